@@ -1,0 +1,74 @@
+"""ctypes binding of libbatchfirst_hip.so (the C ABI in include/batchfirst.h).
+
+The library is the product: if it is missing this module raises, it never falls back to a
+CPU path.  Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C batch_first_amd/csrc``.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbatchfirst_hip.so")
+
+BF_OK, BF_E_ARG, BF_E_HIP, BF_E_FORMAT, BF_E_NOGPU = 0, -1, -2, -3, -4
+
+_c = ctypes
+_vp, _sz, _int = _c.c_void_p, _c.c_size_t, _c.c_int
+
+# name -> (restype, argtypes); must list every symbol include/batchfirst.h declares
+SIGNATURES = {
+    "bf_last_error": (_c.c_char_p, []),
+    "bf_version": (_c.c_char_p, []),
+    "bf_ctx_create": (_int, [_c.POINTER(_vp), _int, _vp, _sz]),
+    "bf_ctx_destroy": (None, [_vp]),
+    "bf_eval_wire": (_int, [_vp, _vp, _sz, _vp, _sz, _vp, _vp]),
+    "bf_eval_structs": (_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
+    "bf_encode_planes_wire": (_int, [_vp, _vp, _sz, _vp, _sz, _vp, _vp]),
+    "bf_encode_planes_structs": (_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
+    "bf_encode_mailbox_wire": (_int, [_vp, _vp, _sz, _vp, _sz, _vp, _vp]),
+    "bf_encode_mailbox_structs": (_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
+    "bf_eval_mailbox": (_int, [_vp, _vp, _sz, _vp, _vp]),
+    "bf_ctx_check": (_int, [_vp, _vp]),
+    "bf_eval_wire_host": (_int, [_vp, _vp, _sz, _vp, _sz, _vp]),
+    "bf_eval_structs_host": (_int, [_vp, _vp, _sz, _vp, _sz, _vp, _c.POINTER(_sz)]),
+    "bf_host_encode_wire": (_int, [_vp, _sz, _vp, _sz, _vp, _vp, _c.POINTER(_sz), _c.POINTER(_sz)]),
+    "bf_packed_floats": (_sz, []),
+    "bf_pack_weights": (_int, [_vp, _sz, _vp, _sz]),
+    # debugging aids, not part of the public header
+    "bf_eval_mailbox_debug": (_int, [_vp, _vp, _sz, _vp, _vp, _vp]),
+    "bf_debug_floats_per_board": (_sz, []),
+}
+
+_lib = None
+
+
+class BatchFirstError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library once; raise if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing: the HIP extension has not been built (run __graft_entry__.build()); "
+            "there is no CPU fallback" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    """Translate a C return code into the exception the boundary documents."""
+    if rc == BF_OK:
+        return
+    msg = load().bf_last_error().decode("utf-8", "replace")
+    if rc in (BF_E_ARG, BF_E_FORMAT):
+        raise ValueError(msg)
+    raise BatchFirstError(msg)

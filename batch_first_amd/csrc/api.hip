@@ -1,0 +1,344 @@
+// C-ABI entry points (include/batchfirst.h): context, device and host evaluation calls.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/batchfirst.h"
+#include "bf_internal.h"
+#include "bf_kernels.h"
+#include "bf_layout.h"
+
+#define BF_HIP(call)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) return bf::fail(BF_E_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+struct bf_ctx {
+    int device = 0;
+    float* d_packed = nullptr;
+    int* d_err = nullptr;
+    // scratch grown on demand; guarded by `mu` (calls on one context are serialised)
+    std::mutex mu;
+    size_t cap_boards = 0;
+    unsigned* d_local_off = nullptr;
+    unsigned* d_block_total = nullptr;
+    uint8_t* d_mailbox = nullptr;
+    // host entry points: own stream, pinned staging, device staging
+    hipStream_t stream = nullptr;
+    size_t cap_in_bytes = 0;
+    unsigned char* h_in = nullptr;   // pinned
+    unsigned char* d_in = nullptr;
+    size_t cap_scores = 0;
+    float* h_scores = nullptr;       // pinned
+    float* d_scores = nullptr;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+int ensure_boards(bf_ctx* c, size_t n) {
+    if (n <= c->cap_boards) return BF_OK;
+    size_t cap = c->cap_boards ? c->cap_boards : 4096;
+    while (cap < n) cap *= 2;
+    if (c->d_local_off) (void)hipFree(c->d_local_off);
+    if (c->d_block_total) (void)hipFree(c->d_block_total);
+    if (c->d_mailbox) (void)hipFree(c->d_mailbox);
+    c->d_local_off = nullptr; c->d_block_total = nullptr; c->d_mailbox = nullptr; c->cap_boards = 0;
+    BF_HIP(hipMalloc(&c->d_local_off, cap * sizeof(unsigned)));
+    BF_HIP(hipMalloc(&c->d_block_total, bf::scan_blocks_for(cap) * sizeof(unsigned) + 16));
+    BF_HIP(hipMalloc(&c->d_mailbox, cap * bf::kMailboxBytes));
+    c->cap_boards = cap;
+    return BF_OK;
+}
+
+int ensure_staging(bf_ctx* c, size_t in_bytes, size_t n_scores) {
+    if (in_bytes > c->cap_in_bytes) {
+        size_t cap = c->cap_in_bytes ? c->cap_in_bytes : (1u << 20);
+        while (cap < in_bytes) cap *= 2;
+        if (c->h_in) (void)hipHostFree(c->h_in);
+        if (c->d_in) (void)hipFree(c->d_in);
+        c->h_in = nullptr; c->d_in = nullptr; c->cap_in_bytes = 0;
+        BF_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_in), cap, hipHostMallocDefault));
+        BF_HIP(hipMalloc(&c->d_in, cap));
+        c->cap_in_bytes = cap;
+    }
+    if (n_scores > c->cap_scores) {
+        size_t cap = c->cap_scores ? c->cap_scores : 4096;
+        while (cap < n_scores) cap *= 2;
+        if (c->h_scores) (void)hipHostFree(c->h_scores);
+        if (c->d_scores) (void)hipFree(c->d_scores);
+        c->h_scores = nullptr; c->d_scores = nullptr; c->cap_scores = 0;
+        BF_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_scores), cap * sizeof(float), hipHostMallocDefault));
+        BF_HIP(hipMalloc(&c->d_scores, cap * sizeof(float)));
+        c->cap_scores = cap;
+    }
+    return BF_OK;
+}
+
+bf::Workspace workspace(bf_ctx* c) { return bf::Workspace{c->d_local_off, c->d_block_total, c->d_err}; }
+
+int read_err_flag(bf_ctx* c, hipStream_t s) {
+    int flag = 0;
+    BF_HIP(hipMemcpyAsync(&flag, c->d_err, sizeof flag, hipMemcpyDeviceToHost, s));
+    BF_HIP(hipStreamSynchronize(s));
+    if (flag) {
+        BF_HIP(hipMemsetAsync(c->d_err, 0, sizeof(int), s));
+        BF_HIP(hipStreamSynchronize(s));
+        if (flag & 2) return bf::fail(BF_E_FORMAT, "wire input holds code 15, which is not a piece code");
+        return bf::fail(BF_E_FORMAT, "wire input: piece_filters length does not match the popcounts of occupied_bbs");
+    }
+    return BF_OK;
+}
+
+constexpr size_t kMaxBoards = (size_t)1 << 26;
+
+int check_common(const bf_ctx* c, size_t n, const char* who) {
+    if (!c) return bf::fail(BF_E_ARG, "%s: null context", who);
+    if (n > kMaxBoards) return bf::fail(BF_E_ARG, "%s: %zu boards exceeds the limit of %zu per call", who, n, kMaxBoards);
+    return BF_OK;
+}
+
+}  // namespace
+
+extern "C" const char* bf_version(void) { return "batchfirst-hip 0.1 gfx950"; }
+
+extern "C" int bf_ctx_create(bf_ctx** out, int device, const float* h_weights, size_t n_floats) {
+    if (!out || !h_weights) return bf::fail(BF_E_ARG, "bf_ctx_create: null pointer");
+    *out = nullptr;
+    if (n_floats != bf::kWeightFloats)
+        return bf::fail(BF_E_ARG, "bf_ctx_create: expected %zu weight floats, got %zu", bf::kWeightFloats, n_floats);
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return bf::fail(BF_E_NOGPU, "bf_ctx_create: no HIP device");
+    if (device < 0 || device >= count) return bf::fail(BF_E_ARG, "bf_ctx_create: device %d of %d", device, count);
+    hipDeviceProp_t prop;
+    BF_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return bf::fail(BF_E_NOGPU, "bf_ctx_create: device %d is %s, this library is built for gfx950 only", device,
+                        prop.gcnArchName);
+    DeviceGuard guard(device);
+    if (!guard.ok) return bf::fail(BF_E_HIP, "bf_ctx_create: hipSetDevice(%d) failed", device);
+
+    bf_ctx* c = new (std::nothrow) bf_ctx;
+    if (!c) return bf::fail(BF_E_ARG, "bf_ctx_create: out of host memory");
+    c->device = device;
+    std::vector<float> packed(bf::kPackedFloats);
+    bf::pack_weights(h_weights, packed.data());
+    auto bail = [&](int code) {
+        bf_ctx_destroy(c);
+        return code;
+    };
+    if (hipMalloc(&c->d_packed, bf::kPackedFloats * sizeof(float)) != hipSuccess)
+        return bail(bf::fail(BF_E_HIP, "bf_ctx_create: hipMalloc of the weight image failed"));
+    if (hipMemcpy(c->d_packed, packed.data(), bf::kPackedFloats * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+        return bail(bf::fail(BF_E_HIP, "bf_ctx_create: weight upload failed"));
+    if (hipMalloc(&c->d_err, 256) != hipSuccess || hipMemset(c->d_err, 0, 256) != hipSuccess)
+        return bail(bf::fail(BF_E_HIP, "bf_ctx_create: flag allocation failed"));
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
+        return bail(bf::fail(BF_E_HIP, "bf_ctx_create: stream creation failed"));
+    *out = c;
+    return BF_OK;
+}
+
+extern "C" void bf_ctx_destroy(bf_ctx* c) {
+    if (!c) return;
+    DeviceGuard guard(c->device);
+    if (c->stream) {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamDestroy(c->stream);
+    }
+    if (c->d_packed) (void)hipFree(c->d_packed);
+    if (c->d_err) (void)hipFree(c->d_err);
+    if (c->d_local_off) (void)hipFree(c->d_local_off);
+    if (c->d_block_total) (void)hipFree(c->d_block_total);
+    if (c->d_mailbox) (void)hipFree(c->d_mailbox);
+    if (c->h_in) (void)hipHostFree(c->h_in);
+    if (c->d_in) (void)hipFree(c->d_in);
+    if (c->h_scores) (void)hipHostFree(c->h_scores);
+    if (c->d_scores) (void)hipFree(c->d_scores);
+    delete c;
+}
+
+// ---- device-pointer entry points -------------------------------------------------------
+
+extern "C" int bf_encode_mailbox_wire(bf_ctx* c, const uint8_t* d_pf, size_t n_bytes, const uint64_t* d_occ, size_t n,
+                                      uint8_t* d_mailbox, void* stream) {
+    if (int r = check_common(c, n, "bf_encode_mailbox_wire")) return r;
+    if (n == 0) return BF_OK;
+    if (!d_occ || !d_mailbox || (!d_pf && n_bytes)) return bf::fail(BF_E_ARG, "bf_encode_mailbox_wire: null pointer");
+    DeviceGuard guard(c->device);
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (int r = ensure_boards(c, n)) return r;
+    BF_HIP(bf::launch_mailbox_from_wire(d_pf, n_bytes, d_occ, n, workspace(c), d_mailbox, (hipStream_t)stream));
+    return BF_OK;
+}
+
+extern "C" int bf_encode_mailbox_structs(bf_ctx* c, const void* d_structs, size_t stride, size_t n,
+                                         uint8_t* d_mailbox, void* stream) {
+    if (int r = check_common(c, n, "bf_encode_mailbox_structs")) return r;
+    if (n == 0) return BF_OK;
+    if (!d_structs || !d_mailbox) return bf::fail(BF_E_ARG, "bf_encode_mailbox_structs: null pointer");
+    if (stride < BF_NODE_EVAL_BYTES) return bf::fail(BF_E_ARG, "bf_encode_mailbox_structs: stride %zu < 82", stride);
+    DeviceGuard guard(c->device);
+    BF_HIP(bf::launch_mailbox_from_structs(d_structs, stride, n, d_mailbox, (hipStream_t)stream));
+    return BF_OK;
+}
+
+extern "C" int bf_encode_planes_wire(bf_ctx* c, const uint8_t* d_pf, size_t n_bytes, const uint64_t* d_occ, size_t n,
+                                     float* d_planes, void* stream) {
+    if (int r = check_common(c, n, "bf_encode_planes_wire")) return r;
+    if (n == 0) return BF_OK;
+    if (!d_occ || !d_planes || (!d_pf && n_bytes)) return bf::fail(BF_E_ARG, "bf_encode_planes_wire: null pointer");
+    DeviceGuard guard(c->device);
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (int r = ensure_boards(c, n)) return r;
+    BF_HIP(bf::launch_planes_from_wire(d_pf, n_bytes, d_occ, n, workspace(c), d_planes, (hipStream_t)stream));
+    return BF_OK;
+}
+
+extern "C" int bf_encode_planes_structs(bf_ctx* c, const void* d_structs, size_t stride, size_t n, float* d_planes,
+                                        void* stream) {
+    if (int r = check_common(c, n, "bf_encode_planes_structs")) return r;
+    if (n == 0) return BF_OK;
+    if (!d_structs || !d_planes) return bf::fail(BF_E_ARG, "bf_encode_planes_structs: null pointer");
+    if (stride < BF_NODE_EVAL_BYTES) return bf::fail(BF_E_ARG, "bf_encode_planes_structs: stride %zu < 82", stride);
+    DeviceGuard guard(c->device);
+    BF_HIP(bf::launch_planes_from_structs(d_structs, stride, n, d_planes, (hipStream_t)stream));
+    return BF_OK;
+}
+
+extern "C" int bf_eval_mailbox(bf_ctx* c, const uint8_t* d_mailbox, size_t n, float* d_scores, void* stream) {
+    if (int r = check_common(c, n, "bf_eval_mailbox")) return r;
+    if (n == 0) return BF_OK;
+    if (!d_mailbox || !d_scores) return bf::fail(BF_E_ARG, "bf_eval_mailbox: null pointer");
+    DeviceGuard guard(c->device);
+    BF_HIP(bf::launch_eval_f32(d_mailbox, n, c->d_packed, d_scores, nullptr, (hipStream_t)stream));
+    return BF_OK;
+}
+
+extern "C" int bf_eval_wire(bf_ctx* c, const uint8_t* d_pf, size_t n_bytes, const uint64_t* d_occ, size_t n,
+                            float* d_scores, void* stream) {
+    if (int r = check_common(c, n, "bf_eval_wire")) return r;
+    if (n == 0) return BF_OK;
+    if (!d_occ || !d_scores || (!d_pf && n_bytes)) return bf::fail(BF_E_ARG, "bf_eval_wire: null pointer");
+    DeviceGuard guard(c->device);
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (int r = ensure_boards(c, n)) return r;
+    BF_HIP(bf::launch_mailbox_from_wire(d_pf, n_bytes, d_occ, n, workspace(c), c->d_mailbox, (hipStream_t)stream));
+    BF_HIP(bf::launch_eval_f32(c->d_mailbox, n, c->d_packed, d_scores, nullptr, (hipStream_t)stream));
+    return BF_OK;
+}
+
+extern "C" int bf_eval_structs(bf_ctx* c, const void* d_structs, size_t stride, size_t n, float* d_scores,
+                               void* stream) {
+    if (int r = check_common(c, n, "bf_eval_structs")) return r;
+    if (n == 0) return BF_OK;
+    if (!d_structs || !d_scores) return bf::fail(BF_E_ARG, "bf_eval_structs: null pointer");
+    if (stride < BF_NODE_EVAL_BYTES) return bf::fail(BF_E_ARG, "bf_eval_structs: stride %zu < 82", stride);
+    DeviceGuard guard(c->device);
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (int r = ensure_boards(c, n)) return r;
+    BF_HIP(bf::launch_mailbox_from_structs(d_structs, stride, n, c->d_mailbox, (hipStream_t)stream));
+    BF_HIP(bf::launch_eval_f32(c->d_mailbox, n, c->d_packed, d_scores, nullptr, (hipStream_t)stream));
+    return BF_OK;
+}
+
+extern "C" int bf_eval_mailbox_debug(bf_ctx* c, const uint8_t* d_mailbox, size_t n, float* d_scores, float* d_debug,
+                                     void* stream) {
+    if (int r = check_common(c, n, "bf_eval_mailbox_debug")) return r;
+    if (n == 0) return BF_OK;
+    if (!d_mailbox || !d_scores || !d_debug) return bf::fail(BF_E_ARG, "bf_eval_mailbox_debug: null pointer");
+    DeviceGuard guard(c->device);
+    BF_HIP(bf::launch_eval_f32(d_mailbox, n, c->d_packed, d_scores, d_debug, (hipStream_t)stream));
+    return BF_OK;
+}
+
+extern "C" size_t bf_debug_floats_per_board(void) { return bf::kDebugFloatsPerBoard; }
+
+extern "C" int bf_ctx_check(bf_ctx* c, void* stream) {
+    if (!c) return bf::fail(BF_E_ARG, "bf_ctx_check: null context");
+    DeviceGuard guard(c->device);
+    return read_err_flag(c, (hipStream_t)stream);
+}
+
+// ---- host-pointer entry points -----------------------------------------------------------
+
+extern "C" int bf_eval_wire_host(bf_ctx* c, const uint8_t* h_pf, size_t n_bytes, const uint64_t* h_occ, size_t n,
+                                 float* h_scores) {
+    if (int r = check_common(c, n, "bf_eval_wire_host")) return r;
+    if (n == 0) return BF_OK;
+    if (!h_occ || !h_scores || (!h_pf && n_bytes)) return bf::fail(BF_E_ARG, "bf_eval_wire_host: null pointer");
+    // validate before touching the GPU: ann_creation_helper.py:41 allows at most 33 codes a board
+    size_t total = 0;
+    for (size_t i = 0; i < n; ++i) total += (size_t)__builtin_popcountll(h_occ[i]);
+    if ((total + 1) / 2 != n_bytes)
+        return bf::fail(BF_E_FORMAT, "bf_eval_wire_host: %zu piece_filters bytes, but the masks select %zu codes (%zu bytes)",
+                        n_bytes, total, (total + 1) / 2);
+    DeviceGuard guard(c->device);
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (int r = ensure_boards(c, n)) return r;
+    const size_t occ_bytes = n * sizeof(uint64_t);
+    const size_t pf_off = (occ_bytes + 15) & ~(size_t)15;
+    if (int r = ensure_staging(c, pf_off + n_bytes + 16, n)) return r;
+    std::memcpy(c->h_in, h_occ, occ_bytes);
+    if (n_bytes) std::memcpy(c->h_in + pf_off, h_pf, n_bytes);
+    BF_HIP(hipMemcpyAsync(c->d_in, c->h_in, pf_off + n_bytes, hipMemcpyHostToDevice, c->stream));
+    BF_HIP(bf::launch_mailbox_from_wire(c->d_in + pf_off, n_bytes, reinterpret_cast<const uint64_t*>(c->d_in), n,
+                                        workspace(c), c->d_mailbox, c->stream));
+    BF_HIP(bf::launch_eval_f32(c->d_mailbox, n, c->d_packed, c->d_scores, nullptr, c->stream));
+    BF_HIP(hipMemcpyAsync(c->h_scores, c->d_scores, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (int r = read_err_flag(c, c->stream)) return r;
+    std::memcpy(h_scores, c->h_scores, n * sizeof(float));
+    return BF_OK;
+}
+
+extern "C" int bf_eval_structs_host(bf_ctx* c, const void* h_structs, size_t stride, const uint8_t* h_mask, size_t n,
+                                    float* h_scores, size_t* n_scored) {
+    if (n_scored) *n_scored = 0;
+    if (int r = check_common(c, n, "bf_eval_structs_host")) return r;
+    if (n == 0) return BF_OK;
+    if (!h_structs || !h_scores) return bf::fail(BF_E_ARG, "bf_eval_structs_host: null pointer");
+    if (stride < BF_NODE_EVAL_BYTES) return bf::fail(BF_E_ARG, "bf_eval_structs_host: stride %zu < 82", stride);
+    DeviceGuard guard(c->device);
+    std::lock_guard<std::mutex> lock(c->mu);
+    // gather the 82 evaluation bytes of every selected record into an 88-byte-stride staging copy
+    constexpr size_t kCompact = 88;
+    size_t m = 0;
+    if (h_mask) {
+        for (size_t j = 0; j < n; ++j) m += h_mask[j] ? 1 : 0;
+    } else {
+        m = n;
+    }
+    if (m == 0) return BF_OK;
+    if (int r = ensure_boards(c, m)) return r;
+    if (int r = ensure_staging(c, m * kCompact, m)) return r;
+    const unsigned char* recs = static_cast<const unsigned char*>(h_structs);
+    size_t k = 0;
+    for (size_t j = 0; j < n; ++j) {
+        if (h_mask && !h_mask[j]) continue;
+        std::memcpy(c->h_in + k * kCompact, recs + j * stride, BF_NODE_EVAL_BYTES);
+        ++k;
+    }
+    BF_HIP(hipMemcpyAsync(c->d_in, c->h_in, m * kCompact, hipMemcpyHostToDevice, c->stream));
+    BF_HIP(bf::launch_mailbox_from_structs(c->d_in, kCompact, m, c->d_mailbox, c->stream));
+    BF_HIP(bf::launch_eval_f32(c->d_mailbox, m, c->d_packed, c->d_scores, nullptr, c->stream));
+    BF_HIP(hipMemcpyAsync(c->h_scores, c->d_scores, m * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    BF_HIP(hipStreamSynchronize(c->stream));
+    std::memcpy(h_scores, c->h_scores, m * sizeof(float));
+    if (n_scored) *n_scored = m;
+    return BF_OK;
+}

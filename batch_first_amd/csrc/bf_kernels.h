@@ -1,0 +1,35 @@
+// Launch wrappers implemented in the .hip translation units.  All of them only enqueue.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace bf {
+
+// Scratch the wire decode needs: per-board nibble offsets (two-level exclusive scan of the
+// popcounts) and the sticky malformed-input flag.
+struct Workspace {
+    unsigned* local_off;    // [n]
+    unsigned* block_total;  // [scan_blocks_for(n)]
+    int* err_flag;          // [1]
+};
+
+size_t scan_blocks_for(size_t n);
+
+hipError_t launch_mailbox_from_wire(const uint8_t* d_nib, size_t n_bytes, const uint64_t* d_occ, size_t n,
+                                    const Workspace& ws, uint8_t* d_mailbox, hipStream_t stream);
+hipError_t launch_mailbox_from_structs(const void* d_structs, size_t stride, size_t n, uint8_t* d_mailbox,
+                                       hipStream_t stream);
+hipError_t launch_planes_from_wire(const uint8_t* d_nib, size_t n_bytes, const uint64_t* d_occ, size_t n,
+                                   const Workspace& ws, float* d_planes, hipStream_t stream);
+hipError_t launch_planes_from_structs(const void* d_structs, size_t stride, size_t n, float* d_planes,
+                                      hipStream_t stream);
+hipError_t launch_planes_from_mailbox(const uint8_t* d_mailbox, size_t n, float* d_planes, hipStream_t stream);
+
+// The value network: mailboxes -> scores.  `d_packed` is the image bf::pack_weights builds.
+// `d_debug` (nullable) receives every intermediate activation, kDebugFloatsPerBoard per board.
+constexpr size_t kDebugFloatsPerBoard = 64 * (236 + 128 + 6 * 32) + 16;
+hipError_t launch_eval_f32(const uint8_t* d_mailbox, size_t n, const float* d_packed, float* d_scores,
+                           float* d_debug, hipStream_t stream);
+
+}  // namespace bf

@@ -1,0 +1,75 @@
+// Shared host/device description of the value network and of the fragment-ordered weight image.
+//
+// The evaluation kernel keeps "channels in rows, squares on lanes": every layer is computed as
+// out^T[channel][square] = W^T[channel][k] * in^T[k][square] with v_mfma_f32_32x32x2_f32, so a
+// finished 32x32 accumulator tile (row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31) is
+// already the B operand of the next layer: register t of a tile is k-step t, lanes 0-31 carry
+// the k of row rowmap(t,0), lanes 32-63 that of rowmap(t,1).  The weights are therefore stored
+// once, on the host, as a linear stream of A fragments in exactly the order one wave consumes
+// them ("k-step" = 64 floats, one per lane; "group" = 4 consecutive k-steps interleaved so a
+// lane reads its 4 floats with one 16-byte load).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace bf {
+
+constexpr int kPlanes = 15;
+constexpr int kNumInputConvs = 9;
+constexpr int kX1Channels = 236;
+constexpr int kX1Regs = 118;  // channel pair (2r, 2r+1) lives in register r: lanes 0-31 / 32-63
+constexpr int kC2 = 512, kC3 = 128, kC4 = 32, kC10 = 16;
+constexpr float kBnEps = 1e-3f;
+
+struct InputConv { int k, dh, dw, ch, chan_base, tiles; };
+// reference: ann_creation_helper.py:211-236, evaluation_ann.py:22
+constexpr InputConv kInputConvs[kNumInputConvs] = {
+    {3, 1, 1, 64, 0, 2},   {3, 2, 2, 32, 64, 1},  {3, 3, 3, 20, 96, 1},
+    {3, 4, 4, 20, 116, 1}, {3, 5, 5, 18, 136, 1}, {3, 6, 6, 18, 154, 1},
+    {3, 7, 7, 16, 172, 1}, {2, 2, 4, 24, 188, 1}, {2, 4, 2, 24, 212, 1}};
+
+constexpr int rowmap(int t, int hl) { return (t & 3) + 8 * (t >> 2) + 4 * hl; }
+
+// ---- canonical blob offsets (floats) -------------------------------------------------
+constexpr size_t kInputKernelFloats(int i) {
+    return (size_t)kInputConvs[i].k * kInputConvs[i].k * kPlanes * kInputConvs[i].ch;
+}
+struct TowerLayer { int k, cin, cout; };
+constexpr TowerLayer kTower[9] = {{1, 236, 512}, {1, 512, 128}, {3, 128, 32}, {3, 32, 32}, {3, 32, 32},
+                                  {3, 32, 32},   {3, 32, 32},   {3, 32, 32},  {8, 32, 16}};
+constexpr size_t kWeightFloats = 333608;
+
+// ---- packed image layout (floats) -----------------------------------------------------
+constexpr int kGroupFloats = 256;  // 64 lanes x 4 k-steps
+// groups per section of the A-fragment stream
+constexpr int kInputTapTiles = 7 * 9 + 9 /*conv0 second tile*/ + 2 * 4;  // 80 (tile,tap) pairs
+constexpr int kInputGroups = kInputTapTiles * 2;                          // 8 k-steps per pair
+constexpr int kGemm1Groups = 30;   // 118 k-steps padded to 120
+constexpr int kGemm2Groups = 16;   // 4 out tiles x 16 k-steps
+constexpr int kC2Tiles = 16;
+constexpr int kPerC2Groups = kGemm1Groups + kGemm2Groups;  // 46
+constexpr int kConvTapGroups = 4;                          // 16 k-steps per tap and 32-ch chunk
+constexpr int kConv4Groups = 4 * 9 * kConvTapGroups;       // 144
+constexpr int kConv59Groups = 5 * 9 * kConvTapGroups;      // 180
+constexpr int kStreamGroups = kInputGroups + kC2Tiles * kPerC2Groups + kConv4Groups + kConv59Groups;  // 1220
+constexpr int kStreamPadGroups = 16;  // prefetch runs this far past the end
+constexpr size_t kStreamFloats = (size_t)(kStreamGroups + kStreamPadGroups) * kGroupFloats;
+
+// bias table: folded batch-norm shift per channel, layers back to back
+constexpr int kBiasX1 = 0, kBiasX2 = 236, kBiasX3 = 748, kBiasX4 = 876;  // x4..x9: 32 each
+constexpr int kBiasX10 = 876 + 6 * 32;                                     // 1068
+constexpr int kLogitW = kBiasX10 + 16;                                     // 1084
+constexpr int kBiasFloats = kLogitW + 16;                                  // 1100 -> pad
+constexpr size_t kBiasFloatsPadded = 1104;
+
+// head image: [half][t*4+cq][lane][4] = W8[sq][ci=rowmap(t,hl)][co=4cq+j] * scale10[co]
+constexpr size_t kHeadFloats = 2 * 64 * 64 * 4;
+
+constexpr size_t kOffStream = 0;
+constexpr size_t kOffBias = kStreamFloats;
+constexpr size_t kOffHead = kOffBias + kBiasFloatsPadded;
+constexpr size_t kPackedFloats = kOffHead + kHeadFloats;
+
+constexpr int kMailboxBytes = 32;
+
+}  // namespace bf

@@ -1,0 +1,170 @@
+// Host-side weight preparation: batch-norm folding and MFMA fragment ordering.
+//
+// Input: the canonical blob (include/batchfirst.h).  Output: the packed image described in
+// bf_layout.h -- an A-fragment stream in consumption order, a per-channel bias table and the
+// head image.  Batch-norm (ann_creation_helper.py:240-246, :312-317; scale=False, eps 1e-3)
+// is folded: W' = W * inv, b' = beta - mean * inv with inv = 1/sqrt(var + eps); the bias goes
+// into the accumulator's initial value inside the kernel.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/batchfirst.h"
+#include "bf_layout.h"
+#include "bf_internal.h"
+
+namespace bf {
+
+namespace {
+
+struct Canonical {
+    const float* in_w[kNumInputConvs];
+    const float *bn_mean[10], *bn_var[10], *bn_beta[10];
+    const float* tower_w[9];
+    const float* logit_w;
+};
+
+Canonical slice(const float* blob) {
+    Canonical c;
+    size_t pos = 0;
+    for (int i = 0; i < kNumInputConvs; ++i) {
+        c.in_w[i] = blob + pos;
+        pos += kInputKernelFloats(i);
+    }
+    auto bn = [&](int idx, int ch) {
+        c.bn_mean[idx] = blob + pos;
+        c.bn_var[idx] = blob + pos + ch;
+        c.bn_beta[idx] = blob + pos + 2 * ch;
+        pos += 3 * (size_t)ch;
+    };
+    bn(0, kX1Channels);
+    for (int j = 0; j < 9; ++j) {
+        c.tower_w[j] = blob + pos;
+        pos += (size_t)kTower[j].k * kTower[j].k * kTower[j].cin * kTower[j].cout;
+        bn(j + 1, kTower[j].cout);
+    }
+    c.logit_w = blob + pos;
+    pos += 16;
+    return c;
+}
+
+// channel (within a 32-row tile) that sits in accumulator row `row` when channel c is kept at
+// register c>>1 of lane half c&1 (so that x1 register r holds channels 2r / 2r+1)
+int pair_channel_of_row(int row) {
+    int hl = (row >> 2) & 1;
+    int t = (row & 3) + 4 * (row >> 3);
+    return 2 * t + hl;
+}
+
+}  // namespace
+
+void pack_weights(const float* blob, float* packed) {
+    const Canonical c = slice(blob);
+    std::memset(packed, 0, kPackedFloats * sizeof(float));
+
+    // folded scale per batch-norm layer
+    std::vector<std::vector<float>> inv(10);
+    const int bn_ch[10] = {236, 512, 128, 32, 32, 32, 32, 32, 32, 16};
+    float* bias = packed + kOffBias;
+    const int bias_off[10] = {kBiasX1, kBiasX2, kBiasX3, kBiasX4, kBiasX4 + 32, kBiasX4 + 64,
+                              kBiasX4 + 96, kBiasX4 + 128, kBiasX4 + 160, kBiasX10};
+    for (int l = 0; l < 10; ++l) {
+        inv[l].resize(bn_ch[l]);
+        for (int ch = 0; ch < bn_ch[l]; ++ch) {
+            float s = 1.0f / std::sqrt(c.bn_var[l][ch] + kBnEps);
+            inv[l][ch] = s;
+            bias[bias_off[l] + ch] = c.bn_beta[l][ch] - c.bn_mean[l][ch] * s;
+        }
+    }
+    for (int co = 0; co < 16; ++co) bias[kLogitW + co] = c.logit_w[co];
+
+    // ---- A-fragment stream -----------------------------------------------------------
+    float* stream = packed + kOffStream;
+    size_t kstep = 0;  // running k-step index; element (kstep, lane) lives at
+                       // stream[(kstep/4)*256 + lane*4 + kstep%4]
+    auto put = [&](int lane, float v) { stream[(kstep >> 2) * kGroupFloats + lane * 4 + (kstep & 3)] = v; };
+
+    // 1. input convs: for conv, for tap, for tile, 8 k-steps (planes s and s+8)
+    for (int i = 0; i < kNumInputConvs; ++i) {
+        const InputConv& cv = kInputConvs[i];
+        for (int tap = 0; tap < cv.k * cv.k; ++tap) {
+            for (int tile = 0; tile < cv.tiles; ++tile) {
+                for (int s = 0; s < 8; ++s) {
+                    for (int lane = 0; lane < 64; ++lane) {
+                        int hl = lane >> 5, row = lane & 31;
+                        int ch = tile * 32 + pair_channel_of_row(row);
+                        int plane = s + 8 * hl;
+                        float v = 0.0f;
+                        if (ch < cv.ch && plane < kPlanes)
+                            v = c.in_w[i][((size_t)tap * kPlanes + plane) * cv.ch + ch] * inv[0][cv.chan_base + ch];
+                        put(lane, v);
+                    }
+                    ++kstep;
+                }
+            }
+        }
+    }
+    // 2. the 1x1 pair, per 32-channel tile of the 512-wide hidden layer
+    for (int c2 = 0; c2 < kC2Tiles; ++c2) {
+        for (int r = 0; r < 120; ++r) {  // 236 -> 512, k-step r = input channels 2r, 2r+1
+            for (int lane = 0; lane < 64; ++lane) {
+                int hl = lane >> 5, co = c2 * 32 + (lane & 31);
+                int ci = 2 * r + hl;
+                float v = (r < kX1Regs) ? c.tower_w[0][(size_t)ci * kC2 + co] * inv[1][co] : 0.0f;
+                put(lane, v);
+            }
+            ++kstep;
+        }
+        for (int c3 = 0; c3 < 4; ++c3) {  // 512 -> 128, k-step t = hidden rows rowmap(t, hl)
+            for (int t = 0; t < 16; ++t) {
+                for (int lane = 0; lane < 64; ++lane) {
+                    int hl = lane >> 5, co = c3 * 32 + (lane & 31);
+                    int ci = c2 * 32 + rowmap(t, hl);
+                    put(lane, c.tower_w[1][(size_t)ci * kC3 + co] * inv[2][co]);
+                }
+                ++kstep;
+            }
+        }
+    }
+    // 3. 3x3 128 -> 32 in four 32-channel chunks, then five 3x3 32 -> 32
+    auto conv3 = [&](const float* w, int cin, int chunk, const std::vector<float>& scale) {
+        for (int tap = 0; tap < 9; ++tap)
+            for (int s = 0; s < 16; ++s) {
+                for (int lane = 0; lane < 64; ++lane) {
+                    int hl = lane >> 5, co = lane & 31;
+                    int ci = chunk * 32 + 2 * s + hl;
+                    put(lane, w[((size_t)tap * cin + ci) * 32 + co] * scale[co]);
+                }
+                ++kstep;
+            }
+    };
+    for (int q = 0; q < 4; ++q) conv3(c.tower_w[2], 128, q, inv[3]);
+    for (int l = 0; l < 5; ++l) conv3(c.tower_w[3 + l], 32, 0, inv[4 + l]);
+
+    // ---- head: 8x8 valid conv as a 2048 -> 16 dense layer --------------------------
+    float* head = packed + kOffHead;
+    for (int half = 0; half < 2; ++half)
+        for (int t = 0; t < 16; ++t)
+            for (int cq = 0; cq < 4; ++cq)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 4; ++j) {
+                        int hl = lane >> 5, sq = half * 32 + (lane & 31);
+                        int ci = rowmap(t, hl), co = 4 * cq + j;
+                        head[(((size_t)half * 64 + t * 4 + cq) * 64 + lane) * 4 + j] =
+                            c.tower_w[8][((size_t)sq * 32 + ci) * 16 + co] * inv[9][co];
+                    }
+}
+
+}  // namespace bf
+
+extern "C" size_t bf_packed_floats(void) { return bf::kPackedFloats; }
+
+extern "C" int bf_pack_weights(const float* h_weights, size_t n_floats, float* h_packed, size_t n_packed) {
+    if (!h_weights || !h_packed) return bf::fail(BF_E_ARG, "bf_pack_weights: null pointer");
+    if (n_floats != bf::kWeightFloats)
+        return bf::fail(BF_E_ARG, "bf_pack_weights: expected %zu weight floats, got %zu", bf::kWeightFloats, n_floats);
+    if (n_packed != bf::kPackedFloats)
+        return bf::fail(BF_E_ARG, "bf_pack_weights: expected room for %zu packed floats, got %zu", bf::kPackedFloats, n_packed);
+    bf::pack_weights(h_weights, h_packed);
+    return BF_OK;
+}

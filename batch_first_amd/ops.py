@@ -1,0 +1,166 @@
+"""PyTorch-ROCm custom ops over the C ABI: device tensors in, device tensors out, on torch's
+current stream.  PyTorch is plumbing here (allocator, streams, torch.distributed); every op body
+is one call into libbatchfirst_hip.so.
+
+    torch.ops.batchfirst.eval_wire(ctx, piece_filters u8[B], occupied_bbs i64[N]) -> f32[N]
+    torch.ops.batchfirst.eval_structs(ctx, records u8[N, stride])                 -> f32[N]
+    torch.ops.batchfirst.eval_mailbox(ctx, mailbox u8[N, 32])                      -> f32[N]
+    torch.ops.batchfirst.encode_planes_wire(ctx, piece_filters, occupied_bbs)      -> f32[N,15,8,8]
+    torch.ops.batchfirst.encode_planes_structs(ctx, records)                       -> f32[N,15,8,8]
+    torch.ops.batchfirst.encode_mailbox_wire / encode_mailbox_structs              -> u8[N,32]
+
+``ctx`` is the integer handle of a :class:`DeviceContext`.  occupied_bbs travels as int64
+because torch has no first-class uint64; only the bits matter (the reference's placeholder is
+int64 too, ann_creation_helper.py:51).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .chestimator import _as_blob
+
+_contexts = {}
+
+
+class DeviceContext:
+    """Owns a bf_ctx on one GPU; ``handle`` is what the ops take."""
+
+    def __init__(self, weights, device=0):
+        self._lib = _lib.load()
+        blob = _as_blob(weights)
+        ctx = ctypes.c_void_p()
+        _lib.check(self._lib.bf_ctx_create(ctypes.byref(ctx), int(device), blob.ctypes.data, blob.size))
+        self._ctx = ctx
+        self.device = torch.device("cuda", int(device))
+        self.handle = int(ctx.value)
+        _contexts[self.handle] = self
+
+    def check(self):
+        """Synchronise the current stream and raise ValueError if a wire input was malformed."""
+        _lib.check(self._lib.bf_ctx_check(self._ctx, _stream(self.device)))
+
+    def close(self):
+        if self._ctx is not None:
+            _contexts.pop(self.handle, None)
+            self._lib.bf_ctx_destroy(self._ctx)
+            self._ctx = None
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ctx(handle):
+    try:
+        return _contexts[int(handle)]
+    except KeyError:
+        raise ValueError("unknown batchfirst context handle %r" % (handle,))
+
+
+def _dev(t, dtype, name):
+    if not t.is_cuda:
+        raise ValueError("%s must be a device tensor" % name)
+    if t.dtype != dtype:
+        raise ValueError("%s must have dtype %s" % (name, dtype))
+    return t.contiguous()
+
+
+@torch.library.custom_op("batchfirst::eval_wire", mutates_args=())
+def eval_wire(ctx: int, piece_filters: torch.Tensor, occupied_bbs: torch.Tensor) -> torch.Tensor:
+    c = _ctx(ctx)
+    pf = _dev(piece_filters, torch.uint8, "piece_filters")
+    occ = _dev(occupied_bbs, torch.int64, "occupied_bbs")
+    out = torch.empty(occ.numel(), dtype=torch.float32, device=occ.device)
+    _lib.check(c._lib.bf_eval_wire(c._ctx, pf.data_ptr(), pf.numel(), occ.data_ptr(), occ.numel(), out.data_ptr(),
+                                   _stream(occ.device)))
+    return out
+
+
+@torch.library.custom_op("batchfirst::eval_structs", mutates_args=())
+def eval_structs(ctx: int, records: torch.Tensor) -> torch.Tensor:
+    c = _ctx(ctx)
+    recs = _dev(records, torch.uint8, "records")
+    if recs.dim() != 2:
+        raise ValueError("records must be uint8[N, stride]")
+    out = torch.empty(recs.shape[0], dtype=torch.float32, device=recs.device)
+    _lib.check(c._lib.bf_eval_structs(c._ctx, recs.data_ptr(), recs.shape[1], recs.shape[0], out.data_ptr(),
+                                      _stream(recs.device)))
+    return out
+
+
+@torch.library.custom_op("batchfirst::eval_mailbox", mutates_args=())
+def eval_mailbox(ctx: int, mailbox: torch.Tensor) -> torch.Tensor:
+    c = _ctx(ctx)
+    mb = _dev(mailbox, torch.uint8, "mailbox")
+    if mb.dim() != 2 or mb.shape[1] != 32:
+        raise ValueError("mailbox must be uint8[N, 32]")
+    out = torch.empty(mb.shape[0], dtype=torch.float32, device=mb.device)
+    _lib.check(c._lib.bf_eval_mailbox(c._ctx, mb.data_ptr(), mb.shape[0], out.data_ptr(), _stream(mb.device)))
+    return out
+
+
+@torch.library.custom_op("batchfirst::encode_planes_wire", mutates_args=())
+def encode_planes_wire(ctx: int, piece_filters: torch.Tensor, occupied_bbs: torch.Tensor) -> torch.Tensor:
+    c = _ctx(ctx)
+    pf = _dev(piece_filters, torch.uint8, "piece_filters")
+    occ = _dev(occupied_bbs, torch.int64, "occupied_bbs")
+    out = torch.empty((occ.numel(), 15, 8, 8), dtype=torch.float32, device=occ.device)
+    _lib.check(c._lib.bf_encode_planes_wire(c._ctx, pf.data_ptr(), pf.numel(), occ.data_ptr(), occ.numel(),
+                                            out.data_ptr(), _stream(occ.device)))
+    return out
+
+
+@torch.library.custom_op("batchfirst::encode_planes_structs", mutates_args=())
+def encode_planes_structs(ctx: int, records: torch.Tensor) -> torch.Tensor:
+    c = _ctx(ctx)
+    recs = _dev(records, torch.uint8, "records")
+    if recs.dim() != 2:
+        raise ValueError("records must be uint8[N, stride]")
+    out = torch.empty((recs.shape[0], 15, 8, 8), dtype=torch.float32, device=recs.device)
+    _lib.check(c._lib.bf_encode_planes_structs(c._ctx, recs.data_ptr(), recs.shape[1], recs.shape[0],
+                                               out.data_ptr(), _stream(recs.device)))
+    return out
+
+
+@torch.library.custom_op("batchfirst::encode_mailbox_wire", mutates_args=())
+def encode_mailbox_wire(ctx: int, piece_filters: torch.Tensor, occupied_bbs: torch.Tensor) -> torch.Tensor:
+    c = _ctx(ctx)
+    pf = _dev(piece_filters, torch.uint8, "piece_filters")
+    occ = _dev(occupied_bbs, torch.int64, "occupied_bbs")
+    out = torch.empty((occ.numel(), 32), dtype=torch.uint8, device=occ.device)
+    _lib.check(c._lib.bf_encode_mailbox_wire(c._ctx, pf.data_ptr(), pf.numel(), occ.data_ptr(), occ.numel(),
+                                             out.data_ptr(), _stream(occ.device)))
+    return out
+
+
+@torch.library.custom_op("batchfirst::encode_mailbox_structs", mutates_args=())
+def encode_mailbox_structs(ctx: int, records: torch.Tensor) -> torch.Tensor:
+    c = _ctx(ctx)
+    recs = _dev(records, torch.uint8, "records")
+    if recs.dim() != 2:
+        raise ValueError("records must be uint8[N, stride]")
+    out = torch.empty((recs.shape[0], 32), dtype=torch.uint8, device=recs.device)
+    _lib.check(c._lib.bf_encode_mailbox_structs(c._ctx, recs.data_ptr(), recs.shape[1], recs.shape[0],
+                                                out.data_ptr(), _stream(recs.device)))
+    return out
+
+
+def eval_mailbox_debug(ctx, mailbox):
+    """Scores plus every intermediate activation (testing aid; not a registered op)."""
+    c = _ctx(ctx)
+    mb = _dev(mailbox, torch.uint8, "mailbox")
+    n = mb.shape[0]
+    per = c._lib.bf_debug_floats_per_board()
+    scores = torch.empty(n, dtype=torch.float32, device=mb.device)
+    dbg = torch.zeros((n, per), dtype=torch.float32, device=mb.device)
+    _lib.check(c._lib.bf_eval_mailbox_debug(c._ctx, mb.data_ptr(), n, scores.data_ptr(), dbg.data_ptr(),
+                                            _stream(mb.device)))
+    return scores, dbg
+
+
+def records_to_tensor(structs, device):
+    """View a NumPy array of node records as a uint8[N, stride] device tensor."""
+    raw = np.ascontiguousarray(structs).view(np.uint8).reshape(len(structs), -1)
+    return torch.from_numpy(raw.copy()).to(device)

@@ -1,0 +1,163 @@
+/* batchfirst.h -- C ABI of the MI355X-native Batch-First board-evaluation path.
+ *
+ * One shared library (libbatchfirst_hip.so, built from batch_first_amd/csrc for gfx950).
+ * Plain pointers and sizes only; no torch, numpy or TensorFlow types.  Every entry point
+ * names the reference interface it stands in for (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - return value 0 = ok, negative = error (BF_E_*); bf_last_error() gives the message of
+ *     the calling thread's last failure.
+ *   - "d_" arguments are device pointers on the context's GPU, "h_" arguments host pointers.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).  Device
+ *     entry points only enqueue work on it; they never synchronise.
+ *   - Square numbering, bitboards, colours as in batch_first/__init__.py:176-205
+ *     (a1 = bit 0, h8 = bit 63, occupied_co[0] = black, [1] = white, turn 1 = white).
+ *
+ * Wire format (what the reference's evaluation callables are fed,
+ * batch_first/numba_negamax_zero_window.py:71-105 and :11-19):
+ *   occupied_bbs  uint64[n]   per board: occupied | ep-square bit, byte-swapped when black
+ *                             is to move (mover's frame);
+ *   piece_filters uint8[ceil(S/2)], S = sum of popcounts: one 4-bit code per set bit, boards
+ *                             back to back, ascending square order, even-index code in the
+ *                             HIGH nibble, a trailing 0 nibble when S is odd.
+ *   codes: 0 ep square, 1..6 mover's K Q R B N P, 7 mover's castling rook,
+ *          8..13 opponent's K Q R B N P, 14 opponent's castling rook.
+ *
+ * Node records (batch_first/classes_and_structs.py:7-29): the path reads bytes 0..81 of each
+ * record: pawns@0 knights@8 bishops@16 rooks@24 queens@32 kings@40 occupied_co[2]@48
+ * occupied@64 (all uint64) turn@72 (int8) castling_rights@73 (uint64, unaligned)
+ * ep_square@81 (uint8, 0 = none).  `stride` is the record size in bytes (806 for the
+ * reference's dtype, >= 82 for any compact copy); no alignment is required.
+ *
+ * Planes: float32 [n][15][8][8], planes[b][code][rank][file] = 1.0f for every relevant square
+ * in the mover's frame, else 0.0f (batch_first/anns/ann_creation_helper.py:76-79).
+ *
+ * Weights: one float32 blob, see BF_WEIGHT_FLOATS and batch_first_amd/weights.py:
+ *   9 input-conv kernels HWIO [k][k][15][C_i], C = 64,32,20,20,18,18,16,24,24,
+ *     k = 3 (dilation 1..7) then 2 (dilation 2x4, 4x2)       (ann_creation_helper.py:211-236)
+ *   input batch-norm mean[236], var[236], beta[236]           (ann_creation_helper.py:240-246)
+ *   9 tower layers, each kernel HWIO then mean, var, beta:
+ *     1x1 236->512, 1x1 512->128, 3x3 128->32, 5x 3x3 32->32, 8x8(valid) 32->16
+ *                                                             (evaluation_ann.py:268)
+ *   logit kernel [1][1][16][1]                                (evaluation_ann.py:35-44)
+ *   batch-norm is inference mode, no gamma, epsilon 1e-3; no conv has a bias.
+ */
+#ifndef BATCHFIRST_H
+#define BATCHFIRST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BF_WEIGHT_FLOATS 333608u /* 330356 kernel floats + 3 * 1084 batch-norm floats */
+#define BF_NODE_EVAL_BYTES 82u
+#define BF_PLANES_PER_BOARD 960u /* 15 * 64 floats */
+
+enum {
+    BF_OK = 0,
+    BF_E_ARG = -1,      /* bad argument (null pointer, size mismatch) */
+    BF_E_HIP = -2,      /* a HIP runtime call failed */
+    BF_E_FORMAT = -3,   /* malformed wire input (stream length vs popcounts, code 15) */
+    BF_E_NOGPU = -4     /* no usable gfx950 device */
+};
+
+typedef struct bf_ctx bf_ctx;
+
+/* Thread-local text of the last error returned to this thread ("" if none). */
+const char* bf_last_error(void);
+
+/* Library identification: "batchfirst-hip <version> gfx950". */
+const char* bf_version(void);
+
+/* Create an evaluator on GPU `device`: folds batch-norm into the kernels, arranges them in
+ * MFMA fragment order and uploads them.  Stands in for loading the frozen graph into a
+ * tf.Session: batch_first/chestimator.py:51-52, :10-26. */
+int bf_ctx_create(bf_ctx** out, int device, const float* h_weights, size_t n_floats);
+
+/* Free device memory and streams.  Stands in for closer_fn / sess.close():
+ * batch_first/chestimator.py:72. */
+void bf_ctx_destroy(bf_ctx* ctx);
+
+/* ---- evaluation, device pointers (asynchronous on `stream`) ------------------------- */
+
+/* scores[b] = value_network(planes(board b)) for wire-format input.  Stands in for the graph
+ * run behind board_predictor: input_parser + value_network/Squeeze,
+ * batch_first/chestimator.py:38,55-62; ann_creation_helper.py:21-84; evaluation_ann.py:17-46.
+ * Malformed input sets a sticky flag read by bf_ctx_check(); out-of-range reads are clamped. */
+int bf_eval_wire(bf_ctx* ctx, const uint8_t* d_piece_filters, size_t n_bytes,
+                 const uint64_t* d_occupied_bbs, size_t n, float* d_scores, void* stream);
+
+/* Same scores straight from node records: replaces the host encoder
+ * struct_array_to_ann_inputs (batch_first/numba_negamax_zero_window.py:71-105) plus the
+ * host-to-device copy plus the graph run.  d_mask (nullable) selects records as
+ * to_score_mask does (:183-197); scores are written densely for the selected records in
+ * order, *d_n_scored (nullable, device) receives their count. */
+int bf_eval_structs(bf_ctx* ctx, const void* d_structs, size_t stride, size_t n,
+                    float* d_scores, void* stream);
+
+/* ---- encoding alone, device pointers (for the bit-exact check and the HBM figure) ---- */
+
+/* Wire format -> planes.  Stands in for parse_into_ann_input_inference,
+ * batch_first/anns/ann_creation_helper.py:21-84. */
+int bf_encode_planes_wire(bf_ctx* ctx, const uint8_t* d_piece_filters, size_t n_bytes,
+                          const uint64_t* d_occupied_bbs, size_t n, float* d_planes, void* stream);
+
+/* Node records -> planes: struct_array_to_ann_inputs followed by
+ * parse_into_ann_input_inference in one pass (numba_negamax_zero_window.py:71-105,
+ * ann_creation_helper.py:21-84). */
+int bf_encode_planes_structs(bf_ctx* ctx, const void* d_structs, size_t stride, size_t n,
+                             float* d_planes, void* stream);
+
+/* Node records / wire format -> 4-bit mailboxes, uint8 [n][32]: square 2j in the low nibble of
+ * byte j, square 2j+1 in the high nibble, 15 = square not relevant.  This is the compact
+ * device-side form of the planes that the evaluation kernel consumes.  No reference
+ * counterpart (the reference materialises the float planes). */
+int bf_encode_mailbox_wire(bf_ctx* ctx, const uint8_t* d_piece_filters, size_t n_bytes,
+                           const uint64_t* d_occupied_bbs, size_t n, uint8_t* d_mailbox, void* stream);
+int bf_encode_mailbox_structs(bf_ctx* ctx, const void* d_structs, size_t stride, size_t n,
+                              uint8_t* d_mailbox, void* stream);
+
+/* scores from mailboxes (the network alone). */
+int bf_eval_mailbox(bf_ctx* ctx, const uint8_t* d_mailbox, size_t n, float* d_scores, void* stream);
+
+/* Synchronise `stream` and report the sticky malformed-input flag (then clear it). */
+int bf_ctx_check(bf_ctx* ctx, void* stream);
+
+/* ---- evaluation, host pointers (synchronous; what the Python callable uses) --------- */
+
+/* board_predictor(piece_filters, occupied_bbs) -> float32[n]
+ * (batch_first/chestimator.py:38; caller batch_first/numba_negamax_zero_window.py:191-197).
+ * Validates the stream length against the popcounts, copies in, evaluates, copies out.
+ * Re-entrant: calls on one context are serialised internally. */
+int bf_eval_wire_host(bf_ctx* ctx, const uint8_t* h_piece_filters, size_t n_bytes,
+                      const uint64_t* h_occupied_bbs, size_t n, float* h_scores);
+
+/* start_board_evaluations' work without the host encoder
+ * (batch_first/numba_negamax_zero_window.py:183-202): gathers the records selected by h_mask
+ * (nullable = all), evaluates them, writes one score per selected record.
+ * *n_scored (nullable) receives the count. */
+int bf_eval_structs_host(bf_ctx* ctx, const void* h_structs, size_t stride, const uint8_t* h_mask,
+                         size_t n, float* h_scores, size_t* n_scored);
+
+/* ---- host-only helpers (no GPU needed) ----------------------------------------------- */
+
+/* The host encoder itself, for callers that still want the wire format:
+ * struct_array_to_ann_inputs (batch_first/numba_negamax_zero_window.py:71-105).
+ * h_piece_filters must hold ceil(33*n_selected/2)+1 bytes.  Returns the number of stream
+ * bytes through *n_bytes and the number of boards through *n_scored. */
+int bf_host_encode_wire(const void* h_structs, size_t stride, const uint8_t* h_mask, size_t n,
+                        uint8_t* h_piece_filters, uint64_t* h_occupied_bbs,
+                        size_t* n_bytes, size_t* n_scored);
+
+/* Size in floats of the fragment-ordered weight image the kernels read, and the image itself
+ * (bf_ctx_create uploads exactly this).  Exposed so the arrangement can be checked on a CPU. */
+size_t bf_packed_floats(void);
+int bf_pack_weights(const float* h_weights, size_t n_floats, float* h_packed, size_t n_packed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BATCHFIRST_H */

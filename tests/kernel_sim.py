@@ -1,0 +1,167 @@
+"""Lane-level NumPy model of k_eval_f32 (batch_first_amd/csrc/eval_f32.hip).
+
+It walks the packed weight image (bf_pack_weights) exactly as one workgroup does -- same
+k-step order, same register/lane maps for v_mfma_f32_32x32x2_f32 -- so the fragment
+arrangement and the chaining of accumulator tiles can be checked against the oracle on a CPU,
+without a GPU.  Test infrastructure only.
+"""
+import numpy as np
+
+INPUT_CONVS = [(3, 1, 1, 64, 0, 2), (3, 2, 2, 32, 64, 1), (3, 3, 3, 20, 96, 1), (3, 4, 4, 20, 116, 1),
+               (3, 5, 5, 18, 136, 1), (3, 6, 6, 18, 154, 1), (3, 7, 7, 16, 172, 1), (2, 2, 4, 24, 188, 1),
+               (2, 4, 2, 24, 212, 1)]
+STREAM_GROUPS = 1220
+STREAM_PAD = 16
+BIAS_FLOATS = 1104
+B_X1, B_X2, B_X3, B_X4, B_X10, B_LOGIT = 0, 236, 748, 876, 1068, 1084
+
+LANE = np.arange(64)
+HL = LANE >> 5
+LN = LANE & 31
+
+
+def rowmap(t, hl):
+    return (t & 3) + 8 * (t >> 2) + 4 * hl
+
+
+def mfma(a, b, acc):
+    """acc[16][64] += A(32x2) @ B(2x32) with the gfx950 32x32x2 f32 lane maps."""
+    A = a.reshape(2, 32).T.astype(np.float64)   # A[i][k] = a[lane: ln=i, hl=k]
+    B = b.reshape(2, 32).astype(np.float64)     # B[k][j] = b[lane: hl=k, ln=j]
+    D = A @ B
+    for t in range(16):
+        acc[t] += D[rowmap(t, HL), LN]
+
+
+class Stream:
+    def __init__(self, packed):
+        self.data = packed[:(STREAM_GROUPS + STREAM_PAD) * 256].reshape(-1, 64, 4)
+        self.kstep = 0
+
+    def next(self):
+        g, j = divmod(self.kstep, 4)
+        self.kstep += 1
+        return self.data[g, :, j].astype(np.float64)
+
+    def skip(self, n):
+        self.kstep += n
+
+
+def eval_board(packed, mailbox64):
+    """mailbox64: uint8[64] codes (15 = empty) in the mover's frame.  Returns (score, intermediates)."""
+    packed = np.asarray(packed, np.float32)
+    bias = packed[(STREAM_GROUPS + STREAM_PAD) * 256:][:BIAS_FLOATS].astype(np.float64)
+    head = packed[(STREAM_GROUPS + STREAM_PAD) * 256 + BIAS_FLOATS:].reshape(2, 64, 64, 4).astype(np.float64)
+    mb = np.full((22, 22), 255, np.int64)
+    mb[7:15, 7:15] = np.where(mailbox64 == 15, 255, mailbox64).reshape(8, 8)
+
+    inter = {}
+    x1_halves, x3_halves = [], []
+    streams = [Stream(packed), Stream(packed)]
+    # ---- stage 1 + 2 per half (waves are independent here)
+    acc3_h = []
+    for half in range(2):
+        ws = streams[half]
+        sq = 32 * half + LN
+        rank, file = sq >> 3, sq & 7
+        x1 = np.zeros((118, 64))
+        for (k, dh, dw, ch, base, tiles) in INPUT_CONVS:
+            ph, pw = ((k - 1) * dh) // 2, ((k - 1) * dw) // 2
+            acc = np.zeros((tiles, 16, 64))
+            for tile in range(tiles):
+                for t in range(16):
+                    c = 32 * tile + 2 * t
+                    if c < ch:
+                        acc[tile, t] = np.where(HL == 1, bias[B_X1 + base + c + 1], bias[B_X1 + base + c])
+            for tap in range(k * k):
+                dr, df = (tap // k) * dh - ph, (tap % k) * dw - pw
+                cc = mb[rank + 7 + dr, file + 7 + df] - 8 * HL
+                for tile in range(tiles):
+                    for s in range(8):
+                        mfma(ws.next(), (cc == s).astype(np.float64), acc[tile])
+            for tile in range(tiles):
+                for t in range(16):
+                    if 32 * tile + 2 * t < ch:
+                        x1[base // 2 + 16 * tile + t] = np.maximum(acc[tile, t], 0)
+        x1_halves.append(x1)
+        acc3 = np.zeros((4, 16, 64))
+        for c3 in range(4):
+            for t in range(16):
+                acc3[c3, t] = bias[B_X3 + 32 * c3 + rowmap(t, HL)]
+        for c2 in range(16):
+            acc2 = np.zeros((16, 64))
+            for t in range(16):
+                acc2[t] = bias[B_X2 + 32 * c2 + rowmap(t, HL)]
+            for r in range(118):
+                mfma(ws.next(), x1[r], acc2)
+            ws.skip(2)
+            acc2 = np.maximum(acc2, 0)
+            for c3 in range(4):
+                for t in range(16):
+                    mfma(ws.next(), acc2[t], acc3[c3])
+        acc3_h.append(acc3)
+
+    def gather(regs_by_half, nch, chan_of):
+        out = np.zeros((nch, 64))
+        for half in range(2):
+            regs = regs_by_half[half]
+            for r in range(regs.shape[0]):
+                out[chan_of(r, HL), 32 * half + LN] = regs[r]
+        return out
+
+    inter["x1"] = gather(x1_halves, 236, lambda r, hl: 2 * r + hl)
+    x3 = np.zeros((128, 64))
+    for half in range(2):
+        for c3 in range(4):
+            for t in range(16):
+                x3[32 * c3 + rowmap(t, HL), 32 * half + LN] = np.maximum(acc3_h[half][c3, t], 0)
+    inter["x3"] = x3
+
+    # ---- 3x3 layers: LDS plane shared by both halves
+    def conv_chunk(ws, xplane, acc, half):
+        sq = 32 * half + LN
+        rank, file = sq >> 3, sq & 7
+        for tap in range(9):
+            dr, df = tap // 3 - 1, tap % 3 - 1
+            for s in range(16):
+                b = xplane[2 * s + HL, rank + 1 + dr, file + 1 + df]
+                mfma(ws.next(), b, acc)
+
+    def to_plane(x32):  # [32][64] -> zero-haloed [32][10][10]
+        p = np.zeros((32, 10, 10))
+        p[:, 1:9, 1:9] = x32.reshape(32, 8, 8)
+        return p
+
+    accs = [np.zeros((16, 64)), np.zeros((16, 64))]
+    for half in range(2):
+        for t in range(16):
+            accs[half][t] = bias[B_X4 + rowmap(t, HL)]
+    for q in range(4):
+        plane = to_plane(x3[32 * q:32 * q + 32])
+        for half in range(2):
+            conv_chunk(streams[half], plane, accs[half], half)
+    for layer in range(5):
+        x = np.zeros((32, 64))
+        for half in range(2):
+            for t in range(16):
+                x[rowmap(t, HL), 32 * half + LN] = np.maximum(accs[half][t], 0)
+        inter["x%d" % (4 + layer)] = x
+        plane = to_plane(x)
+        for half in range(2):
+            for t in range(16):
+                accs[half][t] = bias[B_X4 + 32 * (layer + 1) + rowmap(t, HL)]
+            conv_chunk(streams[half], plane, accs[half], half)
+    x9 = np.zeros((32, 64))
+    part = np.zeros((128, 16))
+    for half in range(2):
+        for t in range(16):
+            v = np.maximum(accs[half][t], 0)
+            x9[rowmap(t, HL), 32 * half + LN] = v
+            for cq in range(4):
+                part[64 * half + LANE, 4 * cq:4 * cq + 4] += v[:, None] * head[half, t * 4 + cq]
+    inter["x9"] = x9
+    s = part.sum(axis=0)
+    y = np.maximum(s + bias[B_X10:B_X10 + 16], 0)
+    inter["x10"] = y
+    assert streams[0].kstep == STREAM_GROUPS * 4
+    return float((y * bias[B_LOGIT:B_LOGIT + 16]).sum()), inter
