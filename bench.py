@@ -1,0 +1,188 @@
+"""Headline benchmark: board evaluations per second at batch 65536 per GPU (BASELINE.json).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one batch: 65 536 packed node records (88-byte
+stride, resident in HBM) -> record ingest kernel -> fused fp32 evaluation kernel -> 65 536
+scores on the device.  With N > 1 every rank evaluates its own 65 536 boards (weak scaling,
+boards are independent) and the scores are gathered to rank 0 over RCCL inside the step.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH = 65536
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(budget_s=12.0):
+    """The oracle's CPU path (C encoder, single thread as the reference's serial @njit loop, then
+    the torch-CPU fp32 restatement of the graph on all host cores) on a bounded sample."""
+    import torch
+    from batch_first_amd import positions, weights
+    from oracle import encoding, network
+
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "c", "liboracle_encoder.so"))
+    lib.oracle_struct_array_to_ann_inputs.restype = ctypes.c_size_t
+    lib.oracle_struct_array_to_ann_inputs.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
+                                                      ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p,
+                                                      ctypes.c_void_p]
+    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)))
+    torch.set_num_threads(cores)
+    w = weights.make_weights(seed=1234, bn="perturbed")
+    chunk = 1024
+    structs = positions.to_compact(positions.random_structs(chunk, seed=99))
+    raw = np.ascontiguousarray(structs).view(np.uint8)
+    nib = np.zeros(33 * chunk, np.uint8)
+    occ = np.zeros(chunk, np.uint64)
+
+    def one_chunk():
+        nbytes = lib.oracle_struct_array_to_ann_inputs(raw.ctypes.data, structs.dtype.itemsize, None, chunk,
+                                                       nib.ctypes.data, occ.ctypes.data, None)
+        planes = encoding.decode_planes_fast(nib[:nbytes], occ)
+        return network.forward_torch(planes, w)
+
+    one_chunk()  # warm-up (thread pools, oneDNN primitives)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        one_chunk()
+        done += chunk
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or done >= 32 * chunk:
+            break
+    return {"value": done / dt, "unit": "boards/s", "cores": cores, "kind": "port",
+            "sample": "%d boards in chunks of %d: oracle C encoder (1 thread) + torch-CPU fp32 graph (%d threads), %.1f s"
+                      % (done, chunk, cores, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH, help=argparse.SUPPRESS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from batch_first_amd import ops, positions, spec, weights
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = args.batch
+    ctx = ops.DeviceContext(weights.make_weights(seed=1234, bn="perturbed"), device=local_rank)
+    structs = positions.to_compact(positions.random_structs(n, seed=1000 + rank))
+    recs = ops.records_to_tensor(structs, dev)
+    gathered = [torch.empty(n, dtype=torch.float32, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def step():
+        scores = torch.ops.batchfirst.eval_structs(ctx.handle, recs)
+        if world > 1:
+            dist.gather(scores, gathered, dst=0)  # RCCL: scores back to the search host's rank
+        return scores
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        scores = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert bool(torch.isfinite(scores).all())
+
+    # dominant kernel alone (k_eval_f32), HIP events on the stream it is launched on
+    mailbox = torch.ops.batchfirst.encode_mailbox_structs(ctx.handle, recs)
+    torch.ops.batchfirst.eval_mailbox(ctx.handle, mailbox)
+    reps = max(3, min(args.steps, 20))
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(reps):
+        torch.ops.batchfirst.eval_mailbox(ctx.handle, mailbox)
+    ev1.record()
+    torch.cuda.synchronize()
+    kernel_ms = ev0.elapsed_time(ev1) / reps
+    achieved_tflops = spec.FLOPS_PER_BOARD * n / (kernel_ms * 1e-3) / 1e12
+
+    # the encoding kernel alone against HBM (records -> float planes, 88 B in + 3840 B out per board)
+    planes = torch.ops.batchfirst.encode_planes_structs(ctx.handle, recs)
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(reps):
+        planes = torch.ops.batchfirst.encode_planes_structs(ctx.handle, recs)
+    ev1.record()
+    torch.cuda.synchronize()
+    enc_ms = ev0.elapsed_time(ev1) / reps
+    enc_gbs = n * (88 + 3840) / (enc_ms * 1e-3) / 1e9
+    del planes
+
+    if rank == 0:
+        value = world * n * args.steps / elapsed
+        out = {
+            "metric": "board evals/sec at batch 65536",
+            "value": value,
+            "unit": "boards/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: value CNN (9 dilated input convs + tower + logit), "
+                                   "random init, batch %d per GPU, fp32, from packed node records resident in HBM "
+                                   "(fused ingest + conv + head)" % n,
+                       "per_gpu_batch": n, "global_batch": world * n,
+                       "parallelism": "independent shards per GPU" + (", RCCL gather of scores to rank 0" if world > 1 else "")},
+            "roofline": {"bound": "mfma", "kernel": "k_eval_f32", "achieved": achieved_tflops,
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_F32_MFMA_TFLOPS,
+                         "traffic": None, "kernel_ms": kernel_ms,
+                         "flops_per_board": spec.FLOPS_PER_BOARD},
+            "encode_roofline": {"bound": "hbm", "kernel": "k_to_planes<StructSrc>", "achieved": enc_gbs,
+                                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": enc_gbs / PEAK_HBM_GBS,
+                                "kernel_ms": enc_ms, "bytes_per_board": 88 + 3840},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,282 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle and the golden fixtures.
+
+Bars: encoding bit-exact; fp32 scores |g - r| <= 1e-4 * max(|r|, rms(r)) (north_star: 1e-4
+relative; rms floor as in SURVEY.md 8(d) so near-zero scores are not held to an impossible bar).
+"""
+import threading
+
+import numpy as np
+import pytest
+
+from batch_first_amd import positions as P, weights as W
+from oracle import encoding as E, network as N
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-4
+
+
+def _score_ok(got, ref):
+    rms = float(np.sqrt(np.mean(np.asarray(ref, np.float64) ** 2)))
+    bound = REL_TOL * np.maximum(np.abs(ref), rms)
+    return np.all(np.abs(got - ref) <= bound), float(np.max(np.abs(got - ref) / bound))
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+@pytest.fixture(scope="module")
+def ctx(torch_mod):
+    from batch_first_amd import ops
+    c = ops.DeviceContext(W.make_weights(seed=1234, bn="perturbed"), device=0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def predictor():
+    from batch_first_amd import chestimator
+    bp, move_fn, closer = chestimator.get_inference_functions(W.to_blob(W.make_weights(seed=1234, bn="perturbed")))
+    with pytest.raises(NotImplementedError):
+        move_fn()
+    yield bp
+    closer()
+
+
+def _dev_wire(torch, golden, lo=0, hi=None):
+    occ = golden["occupied_bbs"][lo:hi]
+    structs = np.frombuffer(golden["records"].tobytes(), dtype=P.COMPACT_DTYPE)[lo:hi]
+    nib, occ2 = E.struct_array_to_ann_inputs(structs)
+    assert np.array_equal(occ, occ2)
+    return (torch.from_numpy(nib.copy()).cuda(), torch.from_numpy(occ.view(np.int64).copy()).cuda())
+
+
+# ---- encoding: bit-exact -----------------------------------------------------------------
+
+def test_planes_from_wire_bit_exact(torch_mod, ctx, golden):
+    torch = torch_mod
+    pf, occ = _dev_wire(torch, golden)
+    planes = torch.ops.batchfirst.encode_planes_wire(ctx.handle, pf, occ)
+    ctx.check()
+    ref = E.decode_planes_fast(golden["piece_filters"], golden["occupied_bbs"])
+    assert planes.dtype == torch.float32 and tuple(planes.shape) == (1024, 15, 8, 8)
+    assert np.array_equal(planes.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("full_stride", [False, True])
+def test_planes_and_mailbox_from_records_bit_exact(torch_mod, ctx, golden, full_stride):
+    torch = torch_mod
+    from batch_first_amd import ops
+    if full_stride:
+        structs = P.test_set(1024, seed=0)  # 806-byte reference records: unaligned fields
+        assert structs.dtype.itemsize == 806
+        recs = ops.records_to_tensor(structs, "cuda")
+    else:
+        recs = torch.from_numpy(golden["records"].copy()).cuda()
+    planes = torch.ops.batchfirst.encode_planes_structs(ctx.handle, recs)
+    ref = E.decode_planes_fast(golden["piece_filters"], golden["occupied_bbs"])
+    assert np.array_equal(planes.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    mb = torch.ops.batchfirst.encode_mailbox_structs(ctx.handle, recs).cpu().numpy()
+    codes = np.stack([mb & 15, mb >> 4], axis=-1).reshape(len(mb), 64)
+    assert np.array_equal(codes, golden["mailbox"])
+
+
+def test_mailbox_from_wire_and_uneven_splits(torch_mod, ctx, golden):
+    torch = torch_mod
+    # code_testing.py:242-250: the same boards fed in uneven pieces, including a single board
+    edges = [0, 1, 2, 3, 10, 11, 64, 65, 257, 1023, 1024]
+    out = []
+    for a, b in zip(edges[:-1], edges[1:]):
+        pf, occ = _dev_wire(torch, golden, a, b)
+        mb = torch.ops.batchfirst.encode_mailbox_wire(ctx.handle, pf, occ)
+        out.append(mb.cpu().numpy())
+    ctx.check()
+    mb = np.concatenate(out)
+    codes = np.stack([mb & 15, mb >> 4], axis=-1).reshape(len(mb), 64)
+    assert np.array_equal(codes, golden["mailbox"])
+
+
+def test_wire_more_boards_than_one_scan_block(torch_mod, ctx, golden):
+    torch = torch_mod
+    structs = P.random_structs(5000, seed=11)  # the reference's test batch size (code_testing.py:763)
+    nib, occ = E.struct_array_to_ann_inputs(structs)
+    planes = torch.ops.batchfirst.encode_planes_wire(
+        ctx.handle, torch.from_numpy(nib).cuda(), torch.from_numpy(occ.view(np.int64)).cuda())
+    ctx.check()
+    assert np.array_equal(planes.cpu().numpy(), E.decode_planes_fast(nib, occ))
+
+
+def test_empty_inputs(torch_mod, ctx, predictor):
+    torch = torch_mod
+    pf = torch.zeros(0, dtype=torch.uint8, device="cuda")
+    occ = torch.zeros(0, dtype=torch.int64, device="cuda")
+    assert torch.ops.batchfirst.eval_wire(ctx.handle, pf, occ).numel() == 0
+    assert predictor(np.zeros(0, np.uint8), np.zeros(0, np.uint64)).shape == (0,)
+    # a board with no relevant squares at all is legal input for the decoder
+    s = predictor(np.zeros(0, np.uint8), np.zeros(3, np.uint64))
+    assert s.shape == (3,) and np.all(s == s[0]) and np.isfinite(s[0])
+
+
+def test_malformed_wire_is_reported(torch_mod, ctx, predictor, golden):
+    torch = torch_mod
+    nib, occ = golden["piece_filters"], golden["occupied_bbs"]
+    with pytest.raises(ValueError):
+        predictor(nib[:-3], occ)                      # stream too short for the masks
+    with pytest.raises(ValueError):
+        predictor(np.r_[nib, np.zeros(5, np.uint8)], occ)
+    bad = nib.copy()
+    bad[10] = 0xFF                                    # code 15 is not a piece code
+    with pytest.raises(ValueError):
+        predictor(bad, occ)
+    # device entry point: sticky flag, no out-of-bounds read
+    pf = torch.from_numpy(nib[:100].copy()).cuda()
+    oc = torch.from_numpy(occ.view(np.int64).copy()).cuda()
+    torch.ops.batchfirst.encode_mailbox_wire(ctx.handle, pf, oc)
+    with pytest.raises(ValueError):
+        ctx.check()
+    ctx.check()  # flag is cleared by the report
+    # the evaluator still works afterwards
+    assert np.isfinite(predictor(nib, occ)).all()
+
+
+# ---- scores ----------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("bn", ["perturbed", "fresh"])
+def test_scores_match_golden(bn, golden):
+    from batch_first_amd import chestimator
+    bp, _, closer = chestimator.get_inference_functions(W.make_weights(seed=1234, bn=bn))
+    try:
+        got = bp(golden["piece_filters"], golden["occupied_bbs"])
+    finally:
+        closer()
+    assert got.dtype == np.float32 and got.shape == (1024,)
+    ok, worst = _score_ok(got, golden["scores_f32_" + bn])
+    ok64, worst64 = _score_ok(got, golden["scores_f64_" + bn])
+    print("worst error / bound vs f32 oracle %.3f, vs f64 oracle %.3f" % (worst, worst64))
+    assert ok and ok64
+
+
+def test_intermediates_match_oracle(torch_mod, ctx, golden):
+    """Layer-by-layer check through the debug entry point (locates a fault, should one appear)."""
+    torch = torch_mod
+    from batch_first_amd import ops
+    n = 32
+    mbc = golden["mailbox"][:n]
+    mb = (mbc[:, 0::2] | (mbc[:, 1::2] << 4)).astype(np.uint8)
+    scores, dbg = ops.eval_mailbox_debug(ctx.handle, torch.from_numpy(mb).cuda())
+    dbg = dbg.cpu().numpy()
+    planes = E.decode_planes_fast(golden["piece_filters"], golden["occupied_bbs"])[:n]
+    _, inter = N.forward_numpy64(planes, W.make_weights(seed=1234, bn="perturbed"), True)
+    pos = 0
+    for name, ch in [("x1", 236), ("x3", 128), ("x4", 32), ("x5", 32), ("x6", 32), ("x7", 32), ("x8", 32), ("x9", 32)]:
+        got = dbg[:, pos:pos + ch * 64].reshape(n, ch, 8, 8)
+        err = np.max(np.abs(got - inter[name]))
+        assert err < 2e-5, (name, err)
+        pos += ch * 64
+    assert np.max(np.abs(dbg[:, pos:pos + 16] - inter["x10"].reshape(n, 16))) < 2e-5
+    ok, _ = _score_ok(scores.cpu().numpy(), golden["scores_f64_perturbed"][:n])
+    assert ok
+
+
+def test_all_entry_points_agree_bitwise(torch_mod, ctx, predictor, golden):
+    torch = torch_mod
+    pf, occ = _dev_wire(torch, golden)
+    recs = torch.from_numpy(golden["records"].copy()).cuda()
+    a = torch.ops.batchfirst.eval_wire(ctx.handle, pf, occ).cpu().numpy()
+    b = torch.ops.batchfirst.eval_structs(ctx.handle, recs).cpu().numpy()
+    mb = torch.ops.batchfirst.encode_mailbox_structs(ctx.handle, recs)
+    c = torch.ops.batchfirst.eval_mailbox(ctx.handle, mb).cpu().numpy()
+    d = predictor(golden["piece_filters"], golden["occupied_bbs"])
+    structs = np.frombuffer(golden["records"].tobytes(), dtype=P.COMPACT_DTYPE)
+    e = predictor.eval_structs(structs)
+    for other in (b, c, d, e):
+        assert np.array_equal(a.view(np.uint32), other.view(np.uint32))
+    # run-to-run determinism (scores are compared against float32 separators by the search,
+    # numba_negamax_zero_window.py:414)
+    assert np.array_equal(a.view(np.uint32), torch.ops.batchfirst.eval_wire(ctx.handle, pf, occ).cpu().numpy().view(np.uint32))
+
+
+def test_callable_contract(predictor, golden):
+    nib, occ = golden["piece_filters"], golden["occupied_bbs"]
+    n1 = E.popcount(occ[0])
+    one = predictor(nib[:(n1 + 1) // 2].copy(), occ[:1])        # N = 1
+    assert one.shape == (1,)
+    full = predictor(nib, occ)
+    assert one[0] == full[0]
+    # inputs as the TF placeholders declare them: int32 bytes, int64 bit patterns
+    alt = predictor(nib.astype(np.int32), occ.view(np.int64))
+    assert np.array_equal(alt, full)
+    # a strided view, as compress_square_array returns (numba_negamax_zero_window.py:19)
+    strided = np.repeat(nib, 2)[::2]
+    assert not strided.flags["C_CONTIGUOUS"] or strided.base is not None
+    assert np.array_equal(predictor(strided, occ), full)
+    # engine.py:260 subtracts a float32 zero shift from the result
+    shifted = full - np.float32(0.25)
+    assert shifted.dtype == np.float32
+    # mirrored reference FENs evaluate identically (code_testing.py:36-37)
+    assert full[3] == full[4]
+
+
+def test_start_board_evaluations_and_masks(predictor, golden):
+    from batch_first_amd import encoder
+    structs = P.test_set(1024, seed=0)
+    mask = np.arange(1024) % 3 != 0
+    t, scores = encoder.start_board_evaluations(structs, mask, predictor)
+    t.join()
+    full = predictor(golden["piece_filters"], golden["occupied_bbs"])
+    assert np.array_equal(scores, full[mask])
+    # through the wire format and a plain callable wrapper (what engine.py:260 builds)
+    t2, scores2 = encoder.start_board_evaluations(structs, mask, lambda *a: predictor(*a) - np.float32(0))
+    t2.join()
+    assert np.array_equal(scores2, scores)
+
+
+def test_concurrent_callers(predictor, golden):
+    """The search calls the evaluator from worker threads (numba_negamax_zero_window.py:178,199)."""
+    structs = np.frombuffer(golden["records"].tobytes(), dtype=P.COMPACT_DTYPE)
+    full = predictor(golden["piece_filters"], golden["occupied_bbs"])
+    results, errors = {}, []
+
+    def work(k, lo, hi):
+        try:
+            for _ in range(5):
+                results[k] = predictor(*E.struct_array_to_ann_inputs(structs[lo:hi]))
+        except Exception as exc:  # pragma: no cover
+            errors.append(exc)
+
+    spans = [(0, 1024), (5, 6), (100, 613), (900, 1024)]
+    threads = [threading.Thread(target=work, args=(k, lo, hi)) for k, (lo, hi) in enumerate(spans)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors
+    for k, (lo, hi) in enumerate(spans):
+        assert np.array_equal(results[k], full[lo:hi])
+
+
+# ---- full size (BASELINE config 2): properties that do not need the oracle ------------------------
+
+def test_batch_65536_properties(torch_mod, ctx, golden):
+    torch = torch_mod
+    base = golden["records"]                                   # 1024 records
+    recs = torch.from_numpy(np.tile(base, (64, 1))).cuda()    # 65536 records
+    scores = torch.ops.batchfirst.eval_structs(ctx.handle, recs)
+    torch.cuda.synchronize()
+    s = scores.cpu().numpy().reshape(64, 1024)
+    assert np.isfinite(s).all()
+    # every copy of a position gets bit-identical scores wherever it sits in the batch
+    assert np.all(s.view(np.uint32) == s.view(np.uint32)[0:1])
+    ok, _ = _score_ok(s[63], golden["scores_f32_perturbed"])
+    assert ok
+    # planes at full size: exactly one plane per relevant square, none elsewhere
+    planes = torch.ops.batchfirst.encode_planes_structs(ctx.handle, recs)
+    per_square = planes.sum(dim=1).reshape(65536, 64)
+    occ = torch.from_numpy(np.tile(golden["occupied_bbs"], 64).view(np.int64).copy()).cuda()
+    bits = ((occ[:, None] >> torch.arange(64, device="cuda")[None, :]) & 1).to(torch.float32)
+    assert torch.equal(per_square, bits)
+    assert float(planes.sum()) == float(bits.sum())
