@@ -92,9 +92,8 @@ int bf_eval_wire(bf_ctx* ctx, const uint8_t* d_piece_filters, size_t n_bytes,
 
 /* Same scores straight from node records: replaces the host encoder
  * struct_array_to_ann_inputs (batch_first/numba_negamax_zero_window.py:71-105) plus the
- * host-to-device copy plus the graph run.  d_mask (nullable) selects records as
- * to_score_mask does (:183-197); scores are written densely for the selected records in
- * order, *d_n_scored (nullable, device) receives their count. */
+ * host-to-device copy plus the graph run.  One score per record, in order (select records on
+ * the host with bf_eval_structs_host's mask, or gather them before the call). */
 int bf_eval_structs(bf_ctx* ctx, const void* d_structs, size_t stride, size_t n,
                     float* d_scores, void* stream);
 
