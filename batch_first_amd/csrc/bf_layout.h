@@ -43,7 +43,12 @@ constexpr size_t kWeightFloats = 333608;
 constexpr int kGroupFloats = 256;  // 64 lanes x 4 k-steps
 // groups per section of the A-fragment stream
 constexpr int kInputTapTiles = 7 * 9 + 9 /*conv0 second tile*/ + 2 * 4;  // 80 (tile,tap) pairs
-constexpr int kInputGroups = kInputTapTiles * 2;                          // 8 k-steps per pair
+// Stage 1 runs on v_mfma_f32_32x32x16_bf16: the one-hot operand is exact in bf16, and the fp32
+// weight is split into three bf16 terms (hi + mid + lo == w exactly), so one (tile, tap) costs
+// three 32-cycle MFMAs instead of eight 64-cycle fp32 ones at unchanged fp32 accuracy.  One
+// group = one MFMA's A fragment (8 bf16 per lane: planes 8h..8h+7 of the lane's channel row).
+constexpr int kInputSplits = 3;
+constexpr int kInputGroups = kInputTapTiles * kInputSplits;               // 240
 constexpr int kGemm1Groups = 30;   // 118 k-steps padded to 120
 constexpr int kGemm2Groups = 16;   // 4 out tiles x 16 k-steps
 constexpr int kC2Tiles = 16;
@@ -51,7 +56,7 @@ constexpr int kPerC2Groups = kGemm1Groups + kGemm2Groups;  // 46
 constexpr int kConvTapGroups = 4;                          // 16 k-steps per tap and 32-ch chunk
 constexpr int kConv4Groups = 4 * 9 * kConvTapGroups;       // 144
 constexpr int kConv59Groups = 5 * 9 * kConvTapGroups;      // 180
-constexpr int kStreamGroups = kInputGroups + kC2Tiles * kPerC2Groups + kConv4Groups + kConv59Groups;  // 1220
+constexpr int kStreamGroups = kInputGroups + kC2Tiles * kPerC2Groups + kConv4Groups + kConv59Groups;  // 1300
 constexpr int kStreamPadGroups = 16;  // prefetch runs this far past the end
 constexpr size_t kStreamFloats = (size_t)(kStreamGroups + kStreamPadGroups) * kGroupFloats;
 

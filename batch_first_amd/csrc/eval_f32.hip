@@ -38,9 +38,19 @@ namespace bf {
 
 namespace {
 
+#ifdef BF_ABL_NOBARRIER
+#define BF_CONV_SYNC() ((void)0)
+#else
+#define BF_CONV_SYNC() __syncthreads()
+#endif
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define BF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-constexpr int RING = 4;               // prefetch depth in groups (1 KiB per wave each)
+#ifndef BF_RING
+#define BF_RING 4
+#endif
+constexpr int RING = BF_RING;              // prefetch depth in groups (1 KiB per wave each)
 constexpr int C2_UNROLL = RING / 2;   // hidden tiles per loop body; 46 * C2_UNROLL % RING == 0
 static_assert((kPerC2Groups * C2_UNROLL) % RING == 0, "loop body must preserve the ring phase");
 static_assert(kInputGroups % RING == 0, "ring phase at loop entry");
@@ -76,14 +86,16 @@ struct WStream {
     __device__ __forceinline__ f32x4 take(int g) {
         const f32x4 v = ring[g % RING];
         ring[g % RING] = *p;
+#ifndef BF_ABL_NOSTREAM
         p += 64;
+#endif
         return v;
     }
 };
 
 constexpr int input_group_base(int conv) {
     int g = 0;
-    for (int i = 0; i < conv; ++i) g += kInputConvs[i].k * kInputConvs[i].k * kInputConvs[i].tiles * 2;
+    for (int i = 0; i < conv; ++i) g += kInputConvs[i].k * kInputConvs[i].k * kInputConvs[i].tiles * kInputSplits;
     return g;
 }
 
@@ -109,22 +121,23 @@ __device__ __forceinline__ void input_conv(WStream& ws, const unsigned char* mb_
 #pragma unroll
     for (int tap = 0; tap < cv.k * cv.k; ++tap) {
         const int dr = (tap / cv.k) * cv.dh - ph, df = (tap % cv.k) * cv.dw - pw;
-        const int cc = (int)mb_center[dr * MB_W + df] - 8 * hl;  // k-step s carries planes s (lo) and s+8 (hi)
-        float b[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) b[s] = (cc == s) ? 1.0f : 0.0f;
+        // B fragment: one-hot over planes 8*hl .. 8*hl+7 of the shifted square's code, as 8 bf16
+        const unsigned cc = (unsigned)((int)mb_center[dr * MB_W + df] - 8 * hl);
+        const unsigned one = (cc < 8u) ? (0x3F80u << ((cc & 1u) * 16u)) : 0u;  // bf16 1.0 in its half
+        u32x4 bu;
+        bu.x = ((cc >> 1) == 0u) ? one : 0u;
+        bu.y = ((cc >> 1) == 1u) ? one : 0u;
+        bu.z = ((cc >> 1) == 2u) ? one : 0u;
+        bu.w = ((cc >> 1) == 3u) ? one : 0u;
+        const bf16x8 b = __builtin_bit_cast(bf16x8, bu);
 #pragma unroll
         for (int tile = 0; tile < cv.tiles; ++tile) {
-            const int g = G0 + (tap * cv.tiles + tile) * 2;
-            const f32x4 w0 = ws.take(g), w1 = ws.take(g + 1);
-            acc[tile] = BF_MFMA(w0.x, b[0], acc[tile]);
-            acc[tile] = BF_MFMA(w0.y, b[1], acc[tile]);
-            acc[tile] = BF_MFMA(w0.z, b[2], acc[tile]);
-            acc[tile] = BF_MFMA(w0.w, b[3], acc[tile]);
-            acc[tile] = BF_MFMA(w1.x, b[4], acc[tile]);
-            acc[tile] = BF_MFMA(w1.y, b[5], acc[tile]);
-            acc[tile] = BF_MFMA(w1.z, b[6], acc[tile]);
-            acc[tile] = BF_MFMA(w1.w, b[7], acc[tile]);
+            const int g = G0 + (tap * cv.tiles + tile) * kInputSplits;
+#pragma unroll
+            for (int sp = 0; sp < kInputSplits; ++sp) {
+                const f32x4 w = ws.take(g + sp);
+                acc[tile] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), b, acc[tile], 0, 0, 0);
+            }
         }
     }
 #pragma unroll
@@ -266,7 +279,7 @@ __global__ __launch_bounds__(128, 2) void k_eval_f32(const uint8_t* __restrict__
         float* xb = lds.xbuf[q & 1];
 #pragma unroll
         for (int t = 0; t < 16; ++t) xb[rowmap(t, hl) * XP_PLANE + wpos] = fmaxf(acc3[q][t], 0.0f);
-        __syncthreads();
+        BF_CONV_SYNC();
         conv3x3_chunk(ws, GC + q * 36, xb + rpos, acc);
     }
 #pragma unroll
@@ -278,7 +291,7 @@ __global__ __launch_bounds__(128, 2) void k_eval_f32(const uint8_t* __restrict__
             xb[rowmap(t, hl) * XP_PLANE + wpos] = v;
             if (DBG) dbg_board[64 * (236 + 128 + 32 * layer) + rowmap(t, hl) * 64 + sq] = v;
         }
-        __syncthreads();
+        BF_CONV_SYNC();
         const float* bl = bias + kBiasX4 + 32 * (layer + 1);
 #pragma unroll
         for (int t = 0; t < 16; ++t) acc[t] = pick(hl, bl[rowmap(t, 0)], bl[rowmap(t, 1)]);
@@ -296,7 +309,11 @@ __global__ __launch_bounds__(128, 2) void k_eval_f32(const uint8_t* __restrict__
         if (DBG) dbg_board[64 * (236 + 128 + 32 * 5) + rowmap(t, hl) * 64 + sq] = v;
 #pragma unroll
         for (int cq = 0; cq < 4; ++cq) {
+#ifdef BF_ABL_NOHEAD
+            const f32x4 w = f32x4{0.5f, 0.25f, 0.125f, 1.0f};
+#else
             const f32x4 w = hw[(t * 4 + cq) * 64];
+#endif
             part[4 * cq + 0] = fmaf(v, w.x, part[4 * cq + 0]);
             part[4 * cq + 1] = fmaf(v, w.y, part[4 * cq + 1]);
             part[4 * cq + 2] = fmaf(v, w.z, part[4 * cq + 2]);

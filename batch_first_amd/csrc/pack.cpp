@@ -56,6 +56,28 @@ int pair_channel_of_row(int row) {
     return 2 * t + hl;
 }
 
+
+uint16_t bf16_rne(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);  // finite inputs only (weights)
+    return (uint16_t)(u >> 16);
+}
+float bf16_to_float(uint16_t b) {
+    uint32_t u = (uint32_t)b << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+// w == hi + mid + lo exactly: each step removes at least 8 significant bits of the remainder
+void split_bf16x3(float w, uint16_t out[3]) {
+    float r = w;
+    for (int i = 0; i < 3; ++i) {
+        out[i] = bf16_rne(r);
+        r -= bf16_to_float(out[i]);
+    }
+}
+
 }  // namespace
 
 void pack_weights(const float* blob, float* packed) {
@@ -84,22 +106,28 @@ void pack_weights(const float* blob, float* packed) {
                        // stream[(kstep/4)*256 + lane*4 + kstep%4]
     auto put = [&](int lane, float v) { stream[(kstep >> 2) * kGroupFloats + lane * 4 + (kstep & 3)] = v; };
 
-    // 1. input convs: for conv, for tap, for tile, 8 k-steps (planes s and s+8)
+    // 1. input convs: for conv, for tap, for tile, three bf16 split terms; one group each.
+    //    Lane (row, h) holds planes 8h..8h+7 of its channel row as 8 bf16 = 4 dwords.
     for (int i = 0; i < kNumInputConvs; ++i) {
         const InputConv& cv = kInputConvs[i];
         for (int tap = 0; tap < cv.k * cv.k; ++tap) {
             for (int tile = 0; tile < cv.tiles; ++tile) {
-                for (int s = 0; s < 8; ++s) {
+                for (int split = 0; split < kInputSplits; ++split) {
+                    uint16_t* grp = reinterpret_cast<uint16_t*>(stream + (kstep >> 2) * kGroupFloats);
                     for (int lane = 0; lane < 64; ++lane) {
-                        int hl = lane >> 5, row = lane & 31;
+                        int h = lane >> 5, row = lane & 31;
                         int ch = tile * 32 + pair_channel_of_row(row);
-                        int plane = s + 8 * hl;
-                        float v = 0.0f;
-                        if (ch < cv.ch && plane < kPlanes)
-                            v = c.in_w[i][((size_t)tap * kPlanes + plane) * cv.ch + ch] * inv[0][cv.chan_base + ch];
-                        put(lane, v);
+                        for (int j = 0; j < 8; ++j) {
+                            int plane = 8 * h + j;
+                            float v = 0.0f;
+                            if (ch < cv.ch && plane < kPlanes)
+                                v = c.in_w[i][((size_t)tap * kPlanes + plane) * cv.ch + ch] * inv[0][cv.chan_base + ch];
+                            uint16_t parts[3];
+                            split_bf16x3(v, parts);
+                            grp[lane * 8 + j] = parts[split];
+                        }
                     }
-                    ++kstep;
+                    kstep += 4;  // one whole group
                 }
             }
         }

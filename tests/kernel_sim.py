@@ -10,7 +10,7 @@ import numpy as np
 INPUT_CONVS = [(3, 1, 1, 64, 0, 2), (3, 2, 2, 32, 64, 1), (3, 3, 3, 20, 96, 1), (3, 4, 4, 20, 116, 1),
                (3, 5, 5, 18, 136, 1), (3, 6, 6, 18, 154, 1), (3, 7, 7, 16, 172, 1), (2, 2, 4, 24, 188, 1),
                (2, 4, 2, 24, 212, 1)]
-STREAM_GROUPS = 1220
+STREAM_GROUPS = 1300
 STREAM_PAD = 16
 BIAS_FLOATS = 1104
 B_X1, B_X2, B_X3, B_X4, B_X10, B_LOGIT = 0, 236, 748, 876, 1068, 1084
@@ -22,6 +22,23 @@ LN = LANE & 31
 
 def rowmap(t, hl):
     return (t & 3) + 8 * (t >> 2) + 4 * hl
+
+
+def mfma_bf16(a8, b8, acc):
+    """acc[16][64] += A(32x16) @ B(16x32), v_mfma_f32_32x32x16_bf16 lane maps:
+    lane (r, h) holds A[row r][k = 8h + j] and B[k = 8h + j][col r], j = 0..7."""
+    A = np.zeros((32, 16))
+    B = np.zeros((16, 32))
+    for h in range(2):
+        A[:, 8 * h:8 * h + 8] = a8[32 * h:32 * h + 32]
+        B[8 * h:8 * h + 8, :] = b8[32 * h:32 * h + 32].T
+    D = A @ B
+    for t in range(16):
+        acc[t] += D[rowmap(t, HL), LN]
+
+
+def bf16_bits_to_float(u16):
+    return (u16.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
 
 
 def mfma(a, b, acc):
@@ -37,6 +54,14 @@ class Stream:
     def __init__(self, packed):
         self.data = packed[:(STREAM_GROUPS + STREAM_PAD) * 256].reshape(-1, 64, 4)
         self.kstep = 0
+
+    def next_group_bf16(self):
+        """One whole group as 8 bf16 per lane (stage 1)."""
+        assert self.kstep % 4 == 0
+        g = self.kstep // 4
+        self.kstep += 4
+        raw = np.ascontiguousarray(self.data[g]).view(np.uint16).reshape(64, 8)
+        return bf16_bits_to_float(raw)
 
     def next(self):
         g, j = divmod(self.kstep, 4)
@@ -76,9 +101,10 @@ def eval_board(packed, mailbox64):
             for tap in range(k * k):
                 dr, df = (tap // k) * dh - ph, (tap % k) * dw - pw
                 cc = mb[rank + 7 + dr, file + 7 + df] - 8 * HL
+                b8 = (cc[:, None] == np.arange(8)[None, :]).astype(np.float64)
                 for tile in range(tiles):
-                    for s in range(8):
-                        mfma(ws.next(), (cc == s).astype(np.float64), acc[tile])
+                    for _split in range(3):
+                        mfma_bf16(ws.next_group_bf16(), b8, acc[tile])
             for tile in range(tiles):
                 for t in range(16):
                     if 32 * tile + 2 * t < ch:

@@ -1,0 +1,11 @@
+#!/bin/bash
+# Build a variant of the library for A/B timing:  tools/build_variant.sh <name> [extra hipcc flags...]
+# Output: build/variants/libbf_<name>.so  (travels to the GPU box; build/ is git-ignored)
+set -e
+name=$1; shift
+root=$(cd "$(dirname "$0")/.." && pwd)
+mkdir -p "$root/build/variants"
+cd "$root/batch_first_amd/csrc"
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -Wno-unused-function "$@" \
+    api.hip encode.hip eval_f32.hip pack.cpp host_encode.cpp -o "$root/build/variants/libbf_$name.so"
+echo "built build/variants/libbf_$name.so"
