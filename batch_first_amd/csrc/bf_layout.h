@@ -57,7 +57,8 @@ constexpr int kConvTapGroups = 4;                          // 16 k-steps per tap
 constexpr int kConv4Groups = 4 * 9 * kConvTapGroups;       // 144
 constexpr int kConv59Groups = 5 * 9 * kConvTapGroups;      // 180
 constexpr int kStreamGroups = kInputGroups + kC2Tiles * kPerC2Groups + kConv4Groups + kConv59Groups;  // 1300
-constexpr int kStreamPadGroups = 16;  // prefetch runs this far past the end
+constexpr int kStreamChunk = 8;       // groups a workgroup walks between two barriers (eval_f32.hip)
+constexpr int kStreamPadGroups = 32;  // prefetch runs up to three chunks past the end
 constexpr size_t kStreamFloats = (size_t)(kStreamGroups + kStreamPadGroups) * kGroupFloats;
 
 // bias table: folded batch-norm shift per channel, layers back to back

@@ -5,29 +5,36 @@
 //   build_convolutional_modules, spec at       evaluation_ann.py:268           (stages 2-4)
 //   logit_layer + squeeze                      evaluation_ann.py:35-46         (stage 5)
 //
-// Shape of the computation.  One workgroup = one board = two waves; wave `half` owns squares
-// 32*half .. 32*half+31 as the 32 columns of every MFMA tile.  All layers run transposed,
+// Shape of the computation.  One board = two waves; wave `half` owns squares 32*half ..
+// 32*half+31 as the 32 columns of every MFMA tile.  All layers run transposed,
 //     out^T[channel][square] += W^T[channel][k] * in^T[k][square]      (v_mfma_f32_32x32x2_f32)
 // so that an accumulator tile (rows = channels in registers, columns = squares on lanes) is
 // directly the B operand of the next 1x1 layer: nothing but the 3x3 layers' halo exchange ever
 // leaves the register file, and no intermediate activation touches HBM.
-//   stage 1  nine dilated input convs as implicit GEMM: B = one-hot of the shifted square's
-//            code built in registers from a padded byte mailbox in LDS; 236 channels end up
-//            in 118 registers (channel 2r on lanes 0-31, 2r+1 on lanes 32-63).
+//   stage 1  nine dilated input convs as implicit GEMM on v_mfma_f32_32x32x16_bf16: B = one-hot
+//            of the shifted square's code (exact in bf16) built in registers from a padded byte
+//            mailbox in LDS, A = the fp32 weight split into three bf16 terms (exact sum), so
+//            fp32 accuracy at 3 x 32 cycles per (tile, tap) instead of 8 x 64.  236 channels
+//            end up in 118 registers (channel 2r on lanes 0-31, 2r+1 on lanes 32-63).
 //   stage 2  1x1 236->512 and 512->128 chained per 32-channel tile of the hidden layer: the
 //            512-wide activation never exists; 128 outputs accumulate in 4 tiles.
 //   stage 3  3x3 128->32: each 32-channel tile goes through a zero-haloed 10x10 LDS plane,
 //            the B operand is a shifted ds_read.
 //   stage 4  five 3x3 32->32 layers the same way.
 //   stage 5  8x8 valid conv (2048->16 dense) + ReLU + logit on the VALU, fixed-order reduction.
-// Weights arrive as a linear stream of A fragments in consumption order (bf_layout.h, pack.cpp),
-// read with one 16-byte load per lane per 4 k-steps through a software prefetch ring; both
-// waves of a board read the same stream (second reader hits L1/L2).  Batch-norm is folded into
-// the weights; its shift initialises the accumulators, so every epilogue is a bare max(x, 0).
 //
-// Cost model: 4848 MFMAs (64 cycles each on one SIMD) per wave and board half; everything else
-// is hidden under them at two waves per SIMD.  Results are bit-reproducible run to run (fixed
-// summation order, no atomics).
+// Weights: a linear stream of A fragments in consumption order (bf_layout.h, pack.cpp).  A
+// workgroup is BPB boards (2*BPB waves) walking the stream in lockstep, CHUNK groups at a
+// time: every wave fetches 1/(2*BPB) of the chunk two chunks ahead into registers, drops it into
+// a 3-slot LDS ring one chunk ahead, and all waves read their A fragments from LDS
+// (ds_read_b128, lane-linear, conflict-free).  One barrier per chunk.  L2 traffic per board is
+// 1/(2*BPB) of what private streaming costs (measured: private streaming of 2.1 MB per board
+// held the kernel 16 % under its matrix-pipe time).  Two workgroups share a CU, so a wave
+// waiting at a barrier leaves its SIMD's matrix pipe to a wave of the other workgroup.
+//
+// Batch-norm is folded into the weights; its shift initialises the accumulators, so every
+// epilogue is a bare max(x, 0).  Results are bit-reproducible run to run and independent of a
+// board's position in the batch (fixed summation order, no atomics).
 #include <hip/hip_runtime.h>
 
 #include "bf_device.h"
@@ -38,24 +45,25 @@ namespace bf {
 
 namespace {
 
-#ifdef BF_ABL_NOBARRIER
-#define BF_CONV_SYNC() ((void)0)
-#else
-#define BF_CONV_SYNC() __syncthreads()
-#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define BF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-#ifndef BF_RING
-#define BF_RING 4
+#ifndef BF_BPB
+#define BF_BPB 2
 #endif
-constexpr int RING = BF_RING;              // prefetch depth in groups (1 KiB per wave each)
-constexpr int C2_UNROLL = RING / 2;   // hidden tiles per loop body; 46 * C2_UNROLL % RING == 0
-static_assert((kPerC2Groups * C2_UNROLL) % RING == 0, "loop body must preserve the ring phase");
-static_assert(kInputGroups % RING == 0, "ring phase at loop entry");
+constexpr int BPB = BF_BPB;            // boards per workgroup
+constexpr int WAVES = 2 * BPB;
+constexpr int THREADS = 64 * WAVES;
+constexpr int CHUNK = kStreamChunk;    // groups per lockstep chunk
+constexpr int SHARE = CHUNK / WAVES;   // groups each wave fetches per chunk
+constexpr int SLOTS = 3;
+constexpr int C2_UNROLL = 4;           // hidden tiles per loop body: 4 * 46 groups = 23 chunks
+static_assert(CHUNK % WAVES == 0, "every wave fetches whole groups");
+static_assert(kInputGroups % CHUNK == 0, "the tile loop must start on a chunk boundary");
+static_assert((kPerC2Groups * C2_UNROLL) % CHUNK == 0, "loop body must be whole chunks");
 static_assert(kC2Tiles % C2_UNROLL == 0, "");
-static_assert(kStreamPadGroups >= RING, "prefetch overrun must stay inside the image");
+static_assert(kStreamPadGroups >= 3 * CHUNK, "prefetch overrun must stay inside the image");
 
 constexpr int MB_W = 22;     // mailbox padded by 7 squares (largest dilation) on every side
 constexpr int MB_BYTES = 496;
@@ -63,33 +71,54 @@ constexpr int XP_W = 10;     // activation plane padded by 1 for the 3x3 layers
 constexpr int XP_PLANE = 100;
 constexpr int XBUF_FLOATS = 32 * XP_PLANE;
 constexpr int RED_STRIDE = 17;
+static_assert(128 * RED_STRIDE <= XBUF_FLOATS, "the head's reduction scratch aliases one activation buffer");
 
 struct Lds {
-    float xbuf[2][XBUF_FLOATS];
-    float red[128 * RED_STRIDE];
-    unsigned char mb[MB_BYTES];
+    f32x4 wring[SLOTS][CHUNK][64];       // shared A-fragment ring
+    float xbuf[BPB][2][XBUF_FLOATS];     // per board: two alternating zero-haloed activation buffers
+    unsigned char mb[BPB][MB_BYTES];     // per board: padded code mailbox
 };
 
-// Software prefetch ring over the A-fragment stream.
+// Lockstep walk over the A-fragment stream through the LDS ring.
 struct WStream {
-    const f32x4* p;  // this lane's slot in the next group to load
-    f32x4 ring[RING];
-    __device__ __forceinline__ void prime(const f32x4* base, int lane) {
-        p = base + lane;
+    const f32x4* src;      // this lane's element of this wave's share of the chunk to fetch next
+    f32x4 stage[SHARE];    // fetched share of the next chunk, not yet in LDS
+    f32x4* ring;           // &lds.wring[0][0][lane]
+    int rd;                // float4 offset of the slot being read
+    int wr_share;          // float4 offset of this wave's share inside a slot
+
+    __device__ __forceinline__ void fetch() {
 #pragma unroll
-        for (int i = 0; i < RING; ++i) {
-            ring[i] = *p;
-            p += 64;
-        }
-    }
-    // g must be a compile-time constant after unrolling; groups are taken in order.
-    __device__ __forceinline__ f32x4 take(int g) {
-        const f32x4 v = ring[g % RING];
-        ring[g % RING] = *p;
+        for (int i = 0; i < SHARE; ++i) stage[i] = src[i * 64];
 #ifndef BF_ABL_NOSTREAM
-        p += 64;
+        src += CHUNK * 64;
 #endif
-        return v;
+    }
+    __device__ __forceinline__ void drop(int slot_off) {
+#pragma unroll
+        for (int i = 0; i < SHARE; ++i) ring[slot_off + wr_share + i * 64] = stage[i];
+    }
+    __device__ __forceinline__ void prime(const f32x4* stream, f32x4* ring_base, int lane, int wave) {
+        ring = ring_base + lane;
+        wr_share = wave * SHARE * 64;
+        src = stream + wave * SHARE * 64 + lane;
+        fetch();                       // chunk 0
+        drop(0);
+        fetch();                       // chunk 1 stays staged
+        rd = (SLOTS - 1) * CHUNK * 64;  // first chunk_step() moves to slot 0
+    }
+    // At every chunk boundary (a fixed place in the code, the same for all waves of the block).
+    __device__ __forceinline__ void chunk_step() {
+        rd = (rd == (SLOTS - 1) * CHUNK * 64) ? 0 : rd + CHUNK * 64;           // slot of chunk k
+        const int wr = (rd == (SLOTS - 1) * CHUNK * 64) ? 0 : rd + CHUNK * 64; // slot of chunk k+1
+        drop(wr);    // its previous content (chunk k-2) was last read before the previous barrier
+        fetch();     // chunk k+2
+        __syncthreads();  // chunk k, dropped by every wave one step ago, is now visible
+    }
+    // g: stream group index, a compile-time constant after unrolling; groups are taken in order.
+    __device__ __forceinline__ f32x4 take(int g) {
+        if (g % CHUNK == 0) chunk_step();
+        return ring[rd + (g % CHUNK) * 64];
     }
 };
 
@@ -103,7 +132,7 @@ __device__ __forceinline__ float pick(int hl, float lo, float hi) { return hl ? 
 
 // Stage 1, one input conv.  reference: ann_creation_helper.py:211-236 (SAME padding:
 // (k-1)*d in total, floor(/2) before).
-template <int I, bool DBG>
+template <int I>
 __device__ __forceinline__ void input_conv(WStream& ws, const unsigned char* mb_center, int hl,
                                            const float* __restrict__ bias, float (&x1)[kX1Regs]) {
     constexpr InputConv cv = kInputConvs[I];
@@ -166,33 +195,37 @@ __device__ __forceinline__ void conv3x3_chunk(WStream& ws, int g0, const float* 
 }
 
 template <bool DBG>
-__global__ __launch_bounds__(128, 2) void k_eval_f32(const uint8_t* __restrict__ mailbox, unsigned n_boards,
-                                                      const f32x4* __restrict__ wstream,
-                                                      const float* __restrict__ bias,
-                                                      const f32x4* __restrict__ headw,
-                                                      float* __restrict__ scores, float* __restrict__ dbg) {
+__global__ __launch_bounds__(THREADS, 2) void k_eval_f32(const uint8_t* __restrict__ mailbox, unsigned n_boards,
+                                                          const f32x4* __restrict__ wstream,
+                                                          const float* __restrict__ bias,
+                                                          const f32x4* __restrict__ headw,
+                                                          float* __restrict__ scores, float* __restrict__ dbg) {
     __shared__ __attribute__((aligned(16))) Lds lds;
-    const unsigned board = blockIdx.x;
-    if (board >= n_boards) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63, hl = lane >> 5, ln = lane & 31;
-    const int half = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bib = wave >> 1, half = wave & 1;           // board in block, half of the board
+    const int btid = tid & 127;                           // thread index within the board
     const int sq = 32 * half + ln, rank = sq >> 3, file = sq & 7;
+    // a trailing odd board is paired with a copy of itself; the copy's score is not stored
+    const unsigned board_raw = blockIdx.x * BPB + bib;
+    const bool live = board_raw < n_boards;
+    const unsigned board = live ? board_raw : n_boards - 1;
 
     WStream ws;
-    ws.prime(wstream, lane);
+    ws.prime(wstream, &lds.wring[0][0][0], lane, wave);
 
     // ---- LDS set-up: empty mailbox (0xFF everywhere), zero activation planes ------------
-    if (tid < MB_BYTES / 4) reinterpret_cast<unsigned*>(lds.mb)[tid] = 0xFFFFFFFFu;
+    if (btid < MB_BYTES / 4) reinterpret_cast<unsigned*>(lds.mb[bib])[btid] = 0xFFFFFFFFu;
     {
-        f32x4* z = reinterpret_cast<f32x4*>(&lds.xbuf[0][0]);
-        for (int i = tid; i < 2 * XBUF_FLOATS / 4; i += 128) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4* z = reinterpret_cast<f32x4*>(&lds.xbuf[bib][0][0]);
+        for (int i = btid; i < 2 * XBUF_FLOATS / 4; i += 128) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
-    if (tid < 64) {
-        const unsigned v = mailbox[(size_t)board * kMailboxBytes + (tid >> 1)];
-        const unsigned c = (tid & 1) ? (v >> 4) : (v & 15u);
-        lds.mb[((tid >> 3) + 7) * MB_W + (tid & 7) + 7] = (unsigned char)(c == 15u ? 0xFFu : c);
+    if (btid < 64) {
+        const unsigned v = mailbox[(size_t)board * kMailboxBytes + (btid >> 1)];
+        const unsigned c = (btid & 1) ? (v >> 4) : (v & 15u);
+        lds.mb[bib][((btid >> 3) + 7) * MB_W + (btid & 7) + 7] = (unsigned char)(c == 15u ? 0xFFu : c);
     }
     __syncthreads();
 
@@ -201,16 +234,16 @@ __global__ __launch_bounds__(128, 2) void k_eval_f32(const uint8_t* __restrict__
     // ---- stage 1: input convs -> x1 (118 registers) -------------------------------------
     float x1[kX1Regs];
     {
-        const unsigned char* mbc = &lds.mb[(rank + 7) * MB_W + file + 7];
-        input_conv<0, DBG>(ws, mbc, hl, bias, x1);
-        input_conv<1, DBG>(ws, mbc, hl, bias, x1);
-        input_conv<2, DBG>(ws, mbc, hl, bias, x1);
-        input_conv<3, DBG>(ws, mbc, hl, bias, x1);
-        input_conv<4, DBG>(ws, mbc, hl, bias, x1);
-        input_conv<5, DBG>(ws, mbc, hl, bias, x1);
-        input_conv<6, DBG>(ws, mbc, hl, bias, x1);
-        input_conv<7, DBG>(ws, mbc, hl, bias, x1);
-        input_conv<8, DBG>(ws, mbc, hl, bias, x1);
+        const unsigned char* mbc = &lds.mb[bib][(rank + 7) * MB_W + file + 7];
+        input_conv<0>(ws, mbc, hl, bias, x1);
+        input_conv<1>(ws, mbc, hl, bias, x1);
+        input_conv<2>(ws, mbc, hl, bias, x1);
+        input_conv<3>(ws, mbc, hl, bias, x1);
+        input_conv<4>(ws, mbc, hl, bias, x1);
+        input_conv<5>(ws, mbc, hl, bias, x1);
+        input_conv<6>(ws, mbc, hl, bias, x1);
+        input_conv<7>(ws, mbc, hl, bias, x1);
+        input_conv<8>(ws, mbc, hl, bias, x1);
     }
     if (DBG) {
 #pragma unroll
@@ -268,7 +301,7 @@ __global__ __launch_bounds__(128, 2) void k_eval_f32(const uint8_t* __restrict__
     }
 
     // ---- stages 3 and 4: the six 3x3 layers through LDS -----------------------------------
-    constexpr int GC = kInputGroups;  // static ring phase after the loop (the loop preserves it)
+    constexpr int GC = kInputGroups;  // static chunk phase after the loop (the loop preserves it)
     const int wpos = (rank + 1) * XP_W + file + 1;           // where this lane's square lives
     const int rpos = hl * XP_PLANE + rank * XP_W + file;     // one row and column back, plane hl
     f32x16 acc;
@@ -276,22 +309,22 @@ __global__ __launch_bounds__(128, 2) void k_eval_f32(const uint8_t* __restrict__
     for (int t = 0; t < 16; ++t) acc[t] = pick(hl, bias[kBiasX4 + rowmap(t, 0)], bias[kBiasX4 + rowmap(t, 1)]);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        float* xb = lds.xbuf[q & 1];
+        float* xb = lds.xbuf[bib][q & 1];
 #pragma unroll
         for (int t = 0; t < 16; ++t) xb[rowmap(t, hl) * XP_PLANE + wpos] = fmaxf(acc3[q][t], 0.0f);
-        BF_CONV_SYNC();
+        __syncthreads();
         conv3x3_chunk(ws, GC + q * 36, xb + rpos, acc);
     }
 #pragma unroll
     for (int layer = 0; layer < 5; ++layer) {
-        float* xb = lds.xbuf[layer & 1];  // continues the 0,1,0,1 alternation of the four chunks above
+        float* xb = lds.xbuf[bib][layer & 1];  // continues the 0,1,0,1 alternation of the four chunks above
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const float v = fmaxf(acc[t], 0.0f);
             xb[rowmap(t, hl) * XP_PLANE + wpos] = v;
             if (DBG) dbg_board[64 * (236 + 128 + 32 * layer) + rowmap(t, hl) * 64 + sq] = v;
         }
-        BF_CONV_SYNC();
+        __syncthreads();
         const float* bl = bias + kBiasX4 + 32 * (layer + 1);
 #pragma unroll
         for (int t = 0; t < 16; ++t) acc[t] = pick(hl, bl[rowmap(t, 0)], bl[rowmap(t, 1)]);
@@ -320,23 +353,26 @@ __global__ __launch_bounds__(128, 2) void k_eval_f32(const uint8_t* __restrict__
             part[4 * cq + 3] = fmaf(v, w.w, part[4 * cq + 3]);
         }
     }
+    // The last 3x3 layer read buffer 0 (layer 4); buffer 1 was last read one barrier earlier,
+    // so its space can hold the reduction scratch (this block is done with the planes).
+    float* red = lds.xbuf[bib][1];
 #pragma unroll
-    for (int co = 0; co < 16; ++co) lds.red[tid * RED_STRIDE + co] = part[co];
+    for (int co = 0; co < 16; ++co) red[btid * RED_STRIDE + co] = part[co];
     __syncthreads();
-    if (tid < 64) {
-        const int co = tid & 15, seg = tid >> 4;
+    if (btid < 64) {
+        const int co = btid & 15, seg = btid >> 4;
         float s = 0.0f;
-        for (int j = 0; j < 32; ++j) s += lds.red[(seg * 32 + j) * RED_STRIDE + co];
+        for (int j = 0; j < 32; ++j) s += red[(seg * 32 + j) * RED_STRIDE + co];
         s += __shfl_xor(s, 16);
         s += __shfl_xor(s, 32);
         const float y = fmaxf(s + bias[kBiasX10 + co], 0.0f);
-        if (DBG && tid < 16) dbg_board[64 * (236 + 128 + 32 * 6) + co] = y;
+        if (DBG && btid < 16) dbg_board[64 * (236 + 128 + 32 * 6) + co] = y;
         float v = y * bias[kLogitW + co];  // logit_layer: no bias, no batch-norm (evaluation_ann.py:35-44)
         v += __shfl_xor(v, 1);
         v += __shfl_xor(v, 2);
         v += __shfl_xor(v, 4);
         v += __shfl_xor(v, 8);
-        if (tid == 0) scores[board] = v;
+        if (btid == 0 && live) scores[board] = v;
     }
 }
 
@@ -348,11 +384,12 @@ hipError_t launch_eval_f32(const uint8_t* d_mailbox, size_t n, const float* d_pa
     const f32x4* ws = reinterpret_cast<const f32x4*>(d_packed + kOffStream);
     const float* bias = d_packed + kOffBias;
     const f32x4* head = reinterpret_cast<const f32x4*>(d_packed + kOffHead);
+    const unsigned blocks = (unsigned)((n + BPB - 1) / BPB);
     if (d_debug)
-        hipLaunchKernelGGL(k_eval_f32<true>, dim3((unsigned)n), dim3(128), 0, stream, d_mailbox, (unsigned)n, ws,
+        hipLaunchKernelGGL(k_eval_f32<true>, dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, (unsigned)n, ws,
                            bias, head, d_scores, d_debug);
     else
-        hipLaunchKernelGGL(k_eval_f32<false>, dim3((unsigned)n), dim3(128), 0, stream, d_mailbox, (unsigned)n, ws,
+        hipLaunchKernelGGL(k_eval_f32<false>, dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, (unsigned)n, ws,
                            bias, head, d_scores, d_debug);
     return hipGetLastError();
 }
