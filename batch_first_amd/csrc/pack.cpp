@@ -138,7 +138,9 @@ void pack_weights(const float* blob, float* packed) {
             for (int lane = 0; lane < 64; ++lane) {
                 int hl = lane >> 5, co = c2 * 32 + (lane & 31);
                 int ci = 2 * r + hl;
-                float v = (r < kX1Regs) ? c.tower_w[0][(size_t)ci * kC2 + co] * inv[1][co] : 0.0f;
+                float v = 0.0f;
+                if (r < kX1Regs) v = c.tower_w[0][(size_t)ci * kC2 + co] * inv[1][co];
+                else if (r == kX1Regs && hl == 0) v = bias[kBiasX2 + co];  // shift rides on a B operand of 1
                 put(lane, v);
             }
             ++kstep;

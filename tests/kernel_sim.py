@@ -116,11 +116,10 @@ def eval_board(packed, mailbox64):
                 acc3[c3, t] = bias[B_X3 + 32 * c3 + rowmap(t, HL)]
         for c2 in range(16):
             acc2 = np.zeros((16, 64))
-            for t in range(16):
-                acc2[t] = bias[B_X2 + 32 * c2 + rowmap(t, HL)]
             for r in range(118):
                 mfma(ws.next(), x1[r], acc2)
-            ws.skip(2)
+            mfma(ws.next(), np.ones(64), acc2)  # k-step 118: the batch-norm shift, B = 1
+            ws.skip(1)
             acc2 = np.maximum(acc2, 0)
             for c3 in range(4):
                 for t in range(16):
