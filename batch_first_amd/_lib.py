@@ -11,6 +11,16 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbatchfirst_hip.so")
 
 BF_OK, BF_E_ARG, BF_E_HIP, BF_E_FORMAT, BF_E_NOGPU = 0, -1, -2, -3, -4
+BF_PRECISION_F32, BF_PRECISION_BF16 = 0, 1
+PRECISIONS = {"f32": BF_PRECISION_F32, "fp32": BF_PRECISION_F32, "float32": BF_PRECISION_F32,
+              "bf16": BF_PRECISION_BF16, "bfloat16": BF_PRECISION_BF16}
+
+
+def precision_code(dtype):
+    try:
+        return PRECISIONS[str(dtype).replace("torch.", "")]
+    except KeyError:
+        raise ValueError("dtype must be 'f32' or 'bf16', got %r" % (dtype,))
 
 _c = ctypes
 _vp, _sz, _int = _c.c_void_p, _c.c_size_t, _c.c_int
@@ -20,6 +30,8 @@ SIGNATURES = {
     "bf_last_error": (_c.c_char_p, []),
     "bf_version": (_c.c_char_p, []),
     "bf_ctx_create": (_int, [_c.POINTER(_vp), _int, _vp, _sz]),
+    "bf_ctx_create_ex": (_int, [_c.POINTER(_vp), _int, _vp, _sz, _int]),
+    "bf_ctx_precision": (_int, [_vp]),
     "bf_ctx_destroy": (None, [_vp]),
     "bf_eval_wire": (_int, [_vp, _vp, _sz, _vp, _sz, _vp, _vp]),
     "bf_eval_structs": (_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
@@ -34,6 +46,8 @@ SIGNATURES = {
     "bf_host_encode_wire": (_int, [_vp, _sz, _vp, _sz, _vp, _vp, _c.POINTER(_sz), _c.POINTER(_sz)]),
     "bf_packed_floats": (_sz, []),
     "bf_pack_weights": (_int, [_vp, _sz, _vp, _sz]),
+    "bf_packed_bf16_bytes": (_sz, []),
+    "bf_pack_weights_bf16": (_int, [_vp, _sz, _vp, _sz]),
     # debugging aids, not part of the public header
     "bf_eval_mailbox_debug": (_int, [_vp, _vp, _sz, _vp, _vp, _vp]),
     "bf_debug_floats_per_board": (_sz, []),

@@ -39,12 +39,14 @@ def _as_blob(weights):
 class BoardPredictor:
     """Callable evaluator bound to one GPU context."""
 
-    def __init__(self, weights, device=0):
+    def __init__(self, weights, device=0, dtype="f32"):
         self._lib = _lib.load()
         blob = _as_blob(weights)
         ctx = ctypes.c_void_p()
-        _lib.check(self._lib.bf_ctx_create(ctypes.byref(ctx), int(device), blob.ctypes.data, blob.size))
+        _lib.check(self._lib.bf_ctx_create_ex(ctypes.byref(ctx), int(device), blob.ctypes.data, blob.size,
+                                              _lib.precision_code(dtype)))
         self._ctx = ctx
+        self.dtype = "bf16" if _lib.precision_code(dtype) == _lib.BF_PRECISION_BF16 else "f32"
         self._closed = False
         self._close_lock = threading.Lock()
         self.device = int(device)
@@ -119,16 +121,17 @@ class BoardPredictor:
             pass
 
 
-def get_inference_functions(weights, session_gpu_memory=.4, device=0):
+def get_inference_functions(weights, session_gpu_memory=.4, device=0, dtype="f32"):
     """(board_predictor, start_move_prediction, closer_fn), as batch_first/chestimator.py:51-74.
 
     ``weights`` replaces ``graphdef_filename``: a ``.npy``/``.npz`` file holding the canonical
     blob (weights.to_blob), the blob itself, or a weights dict.  ``session_gpu_memory`` is
     accepted for call compatibility and ignored (TensorFlow's allocator fraction has no
-    counterpart here).
+    counterpart here).  ``dtype``: "f32" (the parity path) or "bf16" (bf16 operands, float32 sums;
+    include/batchfirst.h, BF_PRECISION_BF16).
     """
     del session_gpu_memory
-    board_predictor = BoardPredictor(weights, device=device)
+    board_predictor = BoardPredictor(weights, device=device, dtype=dtype)
 
     def start_move_prediction(*board_inputs):
         # The policy network (move_evaluation_ann.py) is outside this build's scope (SURVEY.md 8(f) #2).

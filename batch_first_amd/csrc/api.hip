@@ -10,6 +10,7 @@
 #include "bf_internal.h"
 #include "bf_kernels.h"
 #include "bf_layout.h"
+#include "bf_layout_bf16.h"
 
 #define BF_HIP(call)                                                                         \
     do {                                                                                     \
@@ -19,7 +20,9 @@
 
 struct bf_ctx {
     int device = 0;
-    float* d_packed = nullptr;
+    int precision = BF_PRECISION_F32;
+    float* d_packed = nullptr;            // fp32 image (bf_layout.h) when precision == BF_PRECISION_F32
+    unsigned char* d_image16 = nullptr;   // bf16 image (bf_layout_bf16.h) when precision == BF_PRECISION_BF16
     int* d_err = nullptr;
     // scratch grown on demand; guarded by `mu` (calls on one context are serialised)
     std::mutex mu;
@@ -90,6 +93,12 @@ int ensure_staging(bf_ctx* c, size_t in_bytes, size_t n_scores) {
     return BF_OK;
 }
 
+// The value network in the context's precision.
+hipError_t launch_eval(bf_ctx* c, const uint8_t* d_mailbox, size_t n, float* d_scores, float* d_debug, hipStream_t s) {
+    if (c->precision == BF_PRECISION_BF16) return bf::launch_eval_bf16(d_mailbox, n, c->d_image16, d_scores, d_debug, s);
+    return bf::launch_eval_f32(d_mailbox, n, c->d_packed, d_scores, d_debug, s);
+}
+
 bf::Workspace workspace(bf_ctx* c) { return bf::Workspace{c->d_local_off, c->d_block_total, c->d_err}; }
 
 int read_err_flag(bf_ctx* c, hipStream_t s) {
@@ -118,8 +127,16 @@ int check_common(const bf_ctx* c, size_t n, const char* who) {
 extern "C" const char* bf_version(void) { return "batchfirst-hip 0.1 gfx950"; }
 
 extern "C" int bf_ctx_create(bf_ctx** out, int device, const float* h_weights, size_t n_floats) {
+    return bf_ctx_create_ex(out, device, h_weights, n_floats, BF_PRECISION_F32);
+}
+
+extern "C" int bf_ctx_precision(const bf_ctx* c) { return c ? c->precision : BF_E_ARG; }
+
+extern "C" int bf_ctx_create_ex(bf_ctx** out, int device, const float* h_weights, size_t n_floats, int precision) {
     if (!out || !h_weights) return bf::fail(BF_E_ARG, "bf_ctx_create: null pointer");
     *out = nullptr;
+    if (precision != BF_PRECISION_F32 && precision != BF_PRECISION_BF16)
+        return bf::fail(BF_E_ARG, "bf_ctx_create: unknown precision %d", precision);
     if (n_floats != bf::kWeightFloats)
         return bf::fail(BF_E_ARG, "bf_ctx_create: expected %zu weight floats, got %zu", bf::kWeightFloats, n_floats);
     int count = 0;
@@ -136,16 +153,26 @@ extern "C" int bf_ctx_create(bf_ctx** out, int device, const float* h_weights, s
     bf_ctx* c = new (std::nothrow) bf_ctx;
     if (!c) return bf::fail(BF_E_ARG, "bf_ctx_create: out of host memory");
     c->device = device;
-    std::vector<float> packed(bf::kPackedFloats);
-    bf::pack_weights(h_weights, packed.data());
+    c->precision = precision;
     auto bail = [&](int code) {
         bf_ctx_destroy(c);
         return code;
     };
-    if (hipMalloc(&c->d_packed, bf::kPackedFloats * sizeof(float)) != hipSuccess)
-        return bail(bf::fail(BF_E_HIP, "bf_ctx_create: hipMalloc of the weight image failed"));
-    if (hipMemcpy(c->d_packed, packed.data(), bf::kPackedFloats * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
-        return bail(bf::fail(BF_E_HIP, "bf_ctx_create: weight upload failed"));
+    if (precision == BF_PRECISION_BF16) {
+        std::vector<unsigned char> image(bf::b16::kImageBytes);
+        bf::pack_weights_bf16(h_weights, image.data());
+        if (hipMalloc(&c->d_image16, image.size()) != hipSuccess)
+            return bail(bf::fail(BF_E_HIP, "bf_ctx_create: hipMalloc of the weight image failed"));
+        if (hipMemcpy(c->d_image16, image.data(), image.size(), hipMemcpyHostToDevice) != hipSuccess)
+            return bail(bf::fail(BF_E_HIP, "bf_ctx_create: weight upload failed"));
+    } else {
+        std::vector<float> packed(bf::kPackedFloats);
+        bf::pack_weights(h_weights, packed.data());
+        if (hipMalloc(&c->d_packed, bf::kPackedFloats * sizeof(float)) != hipSuccess)
+            return bail(bf::fail(BF_E_HIP, "bf_ctx_create: hipMalloc of the weight image failed"));
+        if (hipMemcpy(c->d_packed, packed.data(), bf::kPackedFloats * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+            return bail(bf::fail(BF_E_HIP, "bf_ctx_create: weight upload failed"));
+    }
     if (hipMalloc(&c->d_err, 256) != hipSuccess || hipMemset(c->d_err, 0, 256) != hipSuccess)
         return bail(bf::fail(BF_E_HIP, "bf_ctx_create: flag allocation failed"));
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
@@ -162,6 +189,7 @@ extern "C" void bf_ctx_destroy(bf_ctx* c) {
         (void)hipStreamDestroy(c->stream);
     }
     if (c->d_packed) (void)hipFree(c->d_packed);
+    if (c->d_image16) (void)hipFree(c->d_image16);
     if (c->d_err) (void)hipFree(c->d_err);
     if (c->d_local_off) (void)hipFree(c->d_local_off);
     if (c->d_block_total) (void)hipFree(c->d_block_total);
@@ -226,7 +254,7 @@ extern "C" int bf_eval_mailbox(bf_ctx* c, const uint8_t* d_mailbox, size_t n, fl
     if (n == 0) return BF_OK;
     if (!d_mailbox || !d_scores) return bf::fail(BF_E_ARG, "bf_eval_mailbox: null pointer");
     DeviceGuard guard(c->device);
-    BF_HIP(bf::launch_eval_f32(d_mailbox, n, c->d_packed, d_scores, nullptr, (hipStream_t)stream));
+    BF_HIP(launch_eval(c, d_mailbox, n, d_scores, nullptr, (hipStream_t)stream));
     return BF_OK;
 }
 
@@ -239,7 +267,7 @@ extern "C" int bf_eval_wire(bf_ctx* c, const uint8_t* d_pf, size_t n_bytes, cons
     std::lock_guard<std::mutex> lock(c->mu);
     if (int r = ensure_boards(c, n)) return r;
     BF_HIP(bf::launch_mailbox_from_wire(d_pf, n_bytes, d_occ, n, workspace(c), c->d_mailbox, (hipStream_t)stream));
-    BF_HIP(bf::launch_eval_f32(c->d_mailbox, n, c->d_packed, d_scores, nullptr, (hipStream_t)stream));
+    BF_HIP(launch_eval(c, c->d_mailbox, n, d_scores, nullptr, (hipStream_t)stream));
     return BF_OK;
 }
 
@@ -253,7 +281,7 @@ extern "C" int bf_eval_structs(bf_ctx* c, const void* d_structs, size_t stride, 
     std::lock_guard<std::mutex> lock(c->mu);
     if (int r = ensure_boards(c, n)) return r;
     BF_HIP(bf::launch_mailbox_from_structs(d_structs, stride, n, c->d_mailbox, (hipStream_t)stream));
-    BF_HIP(bf::launch_eval_f32(c->d_mailbox, n, c->d_packed, d_scores, nullptr, (hipStream_t)stream));
+    BF_HIP(launch_eval(c, c->d_mailbox, n, d_scores, nullptr, (hipStream_t)stream));
     return BF_OK;
 }
 
@@ -263,7 +291,7 @@ extern "C" int bf_eval_mailbox_debug(bf_ctx* c, const uint8_t* d_mailbox, size_t
     if (n == 0) return BF_OK;
     if (!d_mailbox || !d_scores || !d_debug) return bf::fail(BF_E_ARG, "bf_eval_mailbox_debug: null pointer");
     DeviceGuard guard(c->device);
-    BF_HIP(bf::launch_eval_f32(d_mailbox, n, c->d_packed, d_scores, d_debug, (hipStream_t)stream));
+    BF_HIP(launch_eval(c, d_mailbox, n, d_scores, d_debug, (hipStream_t)stream));
     return BF_OK;
 }
 
@@ -299,7 +327,7 @@ extern "C" int bf_eval_wire_host(bf_ctx* c, const uint8_t* h_pf, size_t n_bytes,
     BF_HIP(hipMemcpyAsync(c->d_in, c->h_in, pf_off + n_bytes, hipMemcpyHostToDevice, c->stream));
     BF_HIP(bf::launch_mailbox_from_wire(c->d_in + pf_off, n_bytes, reinterpret_cast<const uint64_t*>(c->d_in), n,
                                         workspace(c), c->d_mailbox, c->stream));
-    BF_HIP(bf::launch_eval_f32(c->d_mailbox, n, c->d_packed, c->d_scores, nullptr, c->stream));
+    BF_HIP(launch_eval(c, c->d_mailbox, n, c->d_scores, nullptr, c->stream));
     BF_HIP(hipMemcpyAsync(c->h_scores, c->d_scores, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     if (int r = read_err_flag(c, c->stream)) return r;
     std::memcpy(h_scores, c->h_scores, n * sizeof(float));
@@ -335,7 +363,7 @@ extern "C" int bf_eval_structs_host(bf_ctx* c, const void* h_structs, size_t str
     }
     BF_HIP(hipMemcpyAsync(c->d_in, c->h_in, m * kCompact, hipMemcpyHostToDevice, c->stream));
     BF_HIP(bf::launch_mailbox_from_structs(c->d_in, kCompact, m, c->d_mailbox, c->stream));
-    BF_HIP(bf::launch_eval_f32(c->d_mailbox, m, c->d_packed, c->d_scores, nullptr, c->stream));
+    BF_HIP(launch_eval(c, c->d_mailbox, m, c->d_scores, nullptr, c->stream));
     BF_HIP(hipMemcpyAsync(c->h_scores, c->d_scores, m * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     BF_HIP(hipStreamSynchronize(c->stream));
     std::memcpy(h_scores, c->h_scores, m * sizeof(float));

@@ -13,6 +13,9 @@ const char* last_error_text();
 // canonical blob -> packed image (bf_layout.h); both sized by the caller
 void pack_weights(const float* blob, float* packed);
 
+// canonical blob -> bf16 image (bf_layout_bf16.h), b16::kImageBytes bytes
+void pack_weights_bf16(const float* blob, unsigned char* image);
+
 // Host restatement of one record's relevance mask and codes, shared by the host encoder.
 // codes_out receives popcount(mask) codes in ascending square order (mover's frame).
 uint64_t host_board_codes(const unsigned char* rec, uint8_t* codes_out, int* n_codes);

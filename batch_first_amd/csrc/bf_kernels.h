@@ -32,4 +32,8 @@ constexpr size_t kDebugFloatsPerBoard = 64 * (236 + 128 + 6 * 32) + 16;
 hipError_t launch_eval_f32(const uint8_t* d_mailbox, size_t n, const float* d_packed, float* d_scores,
                            float* d_debug, hipStream_t stream);
 
+// Same network, bf16 operands with float32 sums; `d_image` is the image bf::pack_weights_bf16 builds.
+hipError_t launch_eval_bf16(const uint8_t* d_mailbox, size_t n, const unsigned char* d_image, float* d_scores,
+                            float* d_debug, hipStream_t stream);
+
 }  // namespace bf

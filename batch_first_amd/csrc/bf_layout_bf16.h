@@ -1,0 +1,79 @@
+// Fragment-ordered weight image of the bf16 evaluation kernel (eval_bf16.hip, pack_bf16.cpp).
+//
+// Arithmetic of the bf16 variant (BASELINE configs[2]; restated on the CPU by
+// oracle/network.py:forward_bf16_model): batch-norm is folded as in the fp32 path
+// (W' = W * inv in float32), W' is rounded to bf16 (round-to-nearest-even), every activation
+// x1..x9 is rounded to bf16 after its ReLU, all sums are float32 (v_mfma_f32_32x32x16_bf16 and
+// v_mfma_f32_16x16x32_bf16), the folded batch-norm shifts stay float32-exact, x10 and the logit
+// are float32.
+//
+// Same orientation as the fp32 kernel: out^T[channel][square] = W^T[channel][k] * in^T[k][square],
+// squares on lanes, one wave = 32 squares of one board.  One "group" = the A fragment of one
+// MFMA = 64 lanes x 8 bf16 = 1 KiB; lane (row, h) holds k = 8h .. 8h+7 of its channel row.
+//
+//   stage 1   per (conv, tap, tile): K = 16 "planes": the 15 one-hot planes + a 16th that is 1.0
+//             on every square, padding included.  Its weights carry the folded shift, split into
+//             three bf16 terms placed in taps 0, 1, 2 (hi + mid + lo == shift exactly), so the
+//             accumulators start from the literal 0.
+//   x1        the 236 channels live in 120 registers per lane (channel pairs on the two lane
+//             halves) = 60 packed dwords = the B operands of 15 k-steps.  Convs 4 and 5 (18
+//             channels) are padded to 20 rows; their 4 padding rows are "ones" channels
+//             (all-zero taps, shift 1.0): k-slots whose B element is exactly 1.0, through which
+//             the 1x1 236->512 layer receives its shift, again as three exact bf16 terms.
+//   1x1 pair  per 32-channel tile of the hidden layer: 15 groups (236->512), 8 groups
+//             (512->128: k-step s = 0,1 x output tile 0..3), 1 padding group.
+//   3x3       per (32-channel input chunk, tap, k-step s): conv4 = 4 x 9 x 2, conv5..9 = 5 x 9 x 2.
+//   head      8x8 valid conv as out[co][board] = sum over (sq, ci): one v_mfma_f32_16x16x32_bf16
+//             per square, A[row = co][k = ci] (separate image, not part of the stream).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include "bf_layout.h"
+
+namespace bf {
+namespace b16 {
+
+constexpr int kGroupBytes = 1024;
+
+// x1 register layout: first register of every input conv, registers per conv (even, so that
+// pairs never straddle a conv)
+constexpr int kX1RegBase[kNumInputConvs] = {0, 32, 48, 58, 68, 78, 88, 96, 108};
+constexpr int kX1RegCount[kNumInputConvs] = {32, 16, 10, 10, 10, 10, 8, 12, 12};
+constexpr int kX1Regs = 120;
+constexpr int kX1Dwords = 60;
+// the two all-ones registers (one per lane half each): conv 4 and conv 5, local register 9
+constexpr int kOnesRegA = 68 + 9, kOnesRegB = 78 + 9;
+
+constexpr int kInputGroups = 80;        // (tile, tap) pairs of stage 1
+constexpr int kGemm1Groups = 15;
+constexpr int kGemm2Groups = 8;
+constexpr int kPerC2Groups = 24;        // 15 + 8 + 1 padding group: two tiles = whole chunks
+constexpr int kC2Tiles = 16;
+constexpr int kConv4Groups = 4 * 9 * 2;   // 72
+constexpr int kConv59Groups = 5 * 9 * 2;  // 90
+constexpr int kGemmBase = kInputGroups;
+constexpr int kConvBase = kGemmBase + kC2Tiles * kPerC2Groups;          // 464
+constexpr int kStreamGroups = kConvBase + kConv4Groups + kConv59Groups;  // 626
+constexpr int kStreamChunkMax = 16;
+constexpr int kStreamPadGroups = 3 * kStreamChunkMax + 14;  // prefetch overrun; total 688 = 43 * 16
+constexpr size_t kStreamBytes = (size_t)(kStreamGroups + kStreamPadGroups) * kGroupBytes;
+
+// float32 shifts that initialise accumulators: x3 (128), x4..x9 (6 x 32), x10 (16), logit weights (16)
+constexpr int kBiasX3 = 0, kBiasX4 = 128, kBiasX10 = 128 + 192, kLogitW = kBiasX10 + 16;
+constexpr int kBiasFloats = kLogitW + 16;  // 352
+constexpr size_t kBiasBytes = kBiasFloats * sizeof(float);
+
+// head image: [sq][lane][8] bf16: lane l holds W8[sq][ci = 8(l>>4) + j][co = l & 15] * inv10[co]
+constexpr size_t kHeadBytes = 64 * 64 * 16;  // 64 KiB
+
+constexpr size_t kOffStream = 0;
+constexpr size_t kOffBias = kStreamBytes;
+constexpr size_t kOffHead = kOffBias + ((kBiasBytes + 255) & ~(size_t)255);
+constexpr size_t kImageBytes = kOffHead + kHeadBytes;
+
+// Which x1 register a (conv, local channel c) lands in, and on which lane half.
+constexpr int x1_reg_of(int conv, int c) { return kX1RegBase[conv] + (c >> 1); }
+
+}  // namespace b16
+}  // namespace bf

@@ -27,11 +27,12 @@ _contexts = {}
 class DeviceContext:
     """Owns a bf_ctx on one GPU; ``handle`` is what the ops take."""
 
-    def __init__(self, weights, device=0):
+    def __init__(self, weights, device=0, dtype="f32"):
         self._lib = _lib.load()
         blob = _as_blob(weights)
         ctx = ctypes.c_void_p()
-        _lib.check(self._lib.bf_ctx_create(ctypes.byref(ctx), int(device), blob.ctypes.data, blob.size))
+        _lib.check(self._lib.bf_ctx_create_ex(ctypes.byref(ctx), int(device), blob.ctypes.data, blob.size,
+                                              _lib.precision_code(dtype)))
         self._ctx = ctx
         self.device = torch.device("cuda", int(device))
         self.handle = int(ctx.value)

@@ -64,6 +64,15 @@ enum {
     BF_E_NOGPU = -4     /* no usable gfx950 device */
 };
 
+/* Arithmetic of the value network inside a context (bf_ctx_create_ex).
+ *   BF_PRECISION_F32   float32 operands and sums (v_mfma_f32_32x32x2_f32): the parity path, scores
+ *                      within 1e-4 relative of the float32 CPU evaluation of the reference's graph.
+ *   BF_PRECISION_BF16  batch-norm-folded weights and every activation x1..x9 rounded to bf16
+ *                      (round-to-nearest-even), float32 sums, shifts, x10 and logit
+ *                      (v_mfma_f32_32x32x16_bf16).  No reference counterpart: the reference runs
+ *                      TensorRT/TensorFlow in FP32 only (ann_creation_helper.py:182-187). */
+enum { BF_PRECISION_F32 = 0, BF_PRECISION_BF16 = 1 };
+
 typedef struct bf_ctx bf_ctx;
 
 /* Thread-local text of the last error returned to this thread ("" if none). */
@@ -76,6 +85,13 @@ const char* bf_version(void);
  * MFMA fragment order and uploads them.  Stands in for loading the frozen graph into a
  * tf.Session: batch_first/chestimator.py:51-52, :10-26. */
 int bf_ctx_create(bf_ctx** out, int device, const float* h_weights, size_t n_floats);
+
+/* bf_ctx_create with a choice of arithmetic (BF_PRECISION_*); bf_ctx_create is the F32 case.
+ * Every evaluation entry point below then runs in that precision; encoding is unaffected. */
+int bf_ctx_create_ex(bf_ctx** out, int device, const float* h_weights, size_t n_floats, int precision);
+
+/* The precision a context was created with. */
+int bf_ctx_precision(const bf_ctx* ctx);
 
 /* Free device memory and streams.  Stands in for closer_fn / sess.close():
  * batch_first/chestimator.py:72. */
@@ -155,6 +171,10 @@ int bf_host_encode_wire(const void* h_structs, size_t stride, const uint8_t* h_m
  * (bf_ctx_create uploads exactly this).  Exposed so the arrangement can be checked on a CPU. */
 size_t bf_packed_floats(void);
 int bf_pack_weights(const float* h_weights, size_t n_floats, float* h_packed, size_t n_packed);
+
+/* The same for the bf16 image (bytes). */
+size_t bf_packed_bf16_bytes(void);
+int bf_pack_weights_bf16(const float* h_weights, size_t n_floats, void* h_image, size_t n_bytes);
 
 #ifdef __cplusplus
 }

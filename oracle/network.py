@@ -123,3 +123,117 @@ def forward_numpy64(planes, weights, return_intermediates=False):
     if return_intermediates:
         return scores, inter
     return scores
+
+
+def bf16_round(a):
+    """float32 -> nearest bf16 (ties to even), returned as float32.  Finite inputs."""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32)
+    u = (u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)
+    return u.view(np.float32)
+
+
+def fold_batch_norm(weights):
+    """(kernels, shifts) with inference batch-norm folded in float32, the way the GPU library's
+    packers do it: W' = W * inv, shift = beta - mean * inv, inv = 1 / sqrt(var + 1e-3).
+    Kernels: the 9 input convs, the 9 tower layers, the logit kernel (untouched).
+    Shifts: one per batch-norm layer (input module, 9 tower layers)."""
+    convs, bns = weights["convs"], weights["bn"]
+    inv, shift = [], []
+    for mean, var, beta in bns:
+        s = (np.float32(1.0) / np.sqrt(var.astype(np.float32) + np.float32(BN_EPS))).astype(np.float32)
+        inv.append(s)
+        shift.append((beta.astype(np.float32) - mean.astype(np.float32) * s).astype(np.float32))
+    kernels = []
+    base = 0
+    for i in range(9):
+        c = convs[i].shape[3]
+        kernels.append((convs[i].astype(np.float32) * inv[0][base:base + c]).astype(np.float32))
+        base += c
+    for j in range(9):
+        kernels.append((convs[9 + j].astype(np.float32) * inv[1 + j]).astype(np.float32))
+    kernels.append(convs[18].astype(np.float32))
+    return kernels, shift
+
+
+def forward_bf16_model(planes, weights, return_intermediates=False, double=False):
+    """CPU model of the library's BF16 precision (include/batchfirst.h, BF_PRECISION_BF16; NO
+    reference counterpart -- the reference evaluates in FP32 only): folded kernels rounded to
+    bf16, every activation x1..x9 rounded to bf16 after its ReLU, float32 (or float64 with
+    ``double``) sums, exact float32 shifts, x10 and the logit unrounded."""
+    import torch
+    import torch.nn.functional as F
+
+    kernels, shift = fold_batch_norm(weights)
+    dt = torch.float64 if double else torch.float32
+    inter = {}
+
+    def t(a):
+        return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dt)
+
+    def conv(x, w_hwio, dil=(1, 1), padding="same"):
+        w = t(np.transpose(bf16_round(w_hwio), (3, 2, 0, 1)))
+        k = w_hwio.shape[0]
+        if padding == "same":
+            pt, pb = _same_pads(k, dil[0])
+            pl, pr = _same_pads(k, dil[1])
+            x = F.pad(x, (pl, pr, pt, pb))
+        return F.conv2d(x, w, dilation=dil)
+
+    def act(x, sh, round_out=True):
+        y = torch.relu(x + t(sh).view(1, -1, 1, 1))
+        if round_out:
+            y = t(bf16_round(y.to(torch.float32).numpy()))
+        return y
+
+    with torch.no_grad():
+        x0 = t(planes)
+        paths = [conv(x0, kernels[i], dil) for i, (_, dil) in enumerate(INPUT_CONV_GEOMETRY)]
+        x = act(torch.cat(paths, dim=1), shift[0])
+        inter["x1"] = x
+        li = 9
+        for section in CONVOLUTIONAL_MODULES[0][0]:
+            padding = "valid" if isinstance(section, tuple) else "same"
+            x = act(conv(x, kernels[li], (1, 1), padding), shift[li - 8], round_out=(padding == "same"))
+            inter["x%d" % (li - 7)] = x
+            li += 1
+        w_logit = t(np.transpose(kernels[18], (3, 2, 0, 1)))
+        scores = F.conv2d(x, w_logit).reshape(-1)
+    if return_intermediates:
+        return scores.to(torch.float32).numpy(), {k: v.to(torch.float32).numpy() for k, v in inter.items()}
+    return scores.to(torch.float32).numpy()
+
+
+def bf16_model_layer(x_in, weights, layer, double=False):
+    """One layer of forward_bf16_model from a given (bf16-valued) input: ``layer`` = "x3" maps x1
+    -> x3 through the fused 1x1 pair (x2 rounded in between), "x4".."x9" map the previous 3x3
+    input, "x10" maps x9 -> x10 (unrounded).  Lets a test follow the GPU layer by layer from the
+    GPU's own inputs, so that one flipped rounding does not grow through later layers."""
+    import torch
+    import torch.nn.functional as F
+
+    kernels, shift = fold_batch_norm(weights)
+    dt = torch.float64 if double else torch.float32
+
+    def t(a):
+        return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dt)
+
+    def step(x, li, padding, round_out):
+        w = t(np.transpose(bf16_round(kernels[li]), (3, 2, 0, 1)))
+        k = kernels[li].shape[0]
+        if padding == "same":
+            p = _same_pads(k, 1)
+            x = F.pad(x, (p[0], p[1], p[0], p[1]))
+        y = torch.relu(F.conv2d(x, w) + t(shift[li - 8]).view(1, -1, 1, 1))
+        if round_out:
+            y = t(bf16_round(y.to(torch.float32).numpy()))
+        return y
+
+    with torch.no_grad():
+        x = t(x_in)
+        if layer == "x3":
+            x = step(step(x, 9, "same", True), 10, "same", True)
+        elif layer == "x10":
+            x = step(x, 17, "valid", False)
+        else:
+            x = step(x, 7 + int(layer[1:]), "same", True)
+    return x.to(torch.float32).numpy()

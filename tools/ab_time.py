@@ -22,6 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=65536)
     ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--dtype", default="f32", help="f32 or bf16: the precision every library's context is created with")
     ap.add_argument("libs", nargs="+")
     args = ap.parse_args()
     import torch
@@ -41,7 +42,7 @@ def main():
                 getattr(lib, fn).restype = res
                 getattr(lib, fn).argtypes = argt
         ctx = ctypes.c_void_p()
-        rc = lib.bf_ctx_create(ctypes.byref(ctx), 0, blob.ctypes.data, blob.size)
+        rc = lib.bf_ctx_create_ex(ctypes.byref(ctx), 0, blob.ctypes.data, blob.size, _lib.precision_code(args.dtype))
         assert rc == 0, lib.bf_last_error()
         libs.append((name, lib, ctx))
     recs = torch.from_numpy(np.ascontiguousarray(positions.to_compact(structs)).view(np.uint8).reshape(args.n, -1).copy()).cuda()
