@@ -11,9 +11,9 @@
 // 32*half .. 32*half+31 as the 32 columns of every v_mfma_f32_32x32x16_bf16 tile, layers run
 // transposed so that a finished accumulator tile, converted to bf16 in place, is the B operand of
 // the next 1x1 layer (k order permuted on the host to match the accumulator's row map).
-//   stage 1  B operand of a tap = the shifted square's one-hot over 16 planes, precomputed once
-//            per board as a 22x22 table of 32-byte entries in LDS: one ds_read_b128 per tap, no
-//            VALU.  The 16th plane is 1.0 everywhere and carries the folded batch-norm shift.
+//   stage 1  B operand of a tap = the shifted square's one-hot over 16 planes: a code byte from a
+//            padded mailbox in LDS, then one ds_read_b128 of that code's row of a 16-entry table.
+//            The 16th plane is 1.0 everywhere and carries the folded batch-norm shift.
 //   stage 2  per 32-channel hidden tile: 15 MFMAs (236->512), ReLU + pack, 8 MFMAs (512->128).
 //   stage 3/4  3x3 layers through zero-haloed [10x10 positions][32 channels] bf16 planes in LDS;
 //            the 16-byte channel chunk c of a position in padded row R sits at chunk (c + R) & 3,
@@ -48,10 +48,19 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr int BPB = BF16_BPB;            // boards per workgroup
 constexpr int WAVES = 2 * BPB;
 constexpr int THREADS = 64 * WAVES;
-constexpr int CHUNK = (BPB >= 4) ? 16 : 8;  // groups per lockstep chunk
+#ifndef BF16_CHUNK
+#define BF16_CHUNK ((BF16_BPB >= 4) ? 16 : 8)
+#endif
+constexpr int CHUNK = BF16_CHUNK;           // groups per lockstep chunk
 constexpr int SHARE = CHUNK / WAVES;        // groups each wave fetches per chunk
-constexpr int SLOTS = 3;
-constexpr int LA = 3;                       // groups held in registers ahead of the MFMA
+#ifndef BF16_SLOTS
+#define BF16_SLOTS 3
+#endif
+constexpr int SLOTS = BF16_SLOTS;           // ring slots: one being read, SLOTS-1 landed or in flight
+#ifndef BF16_LA
+#define BF16_LA 3
+#endif
+constexpr int LA = BF16_LA;                       // groups held in registers ahead of the MFMA
 constexpr int C2_UNROLL = 2;
 static_assert(CHUNK <= kStreamChunkMax, "");
 static_assert(CHUNK % WAVES == 0, "every wave fetches whole groups");
@@ -61,20 +70,46 @@ static_assert((kPerC2Groups * C2_UNROLL) % CHUNK == 0 && (kPerC2Groups * C2_UNRO
 static_assert(kC2Tiles % C2_UNROLL == 0, "");
 static_assert(LA <= CHUNK, "");
 
-constexpr int OH_W = 22;                    // one-hot table: board padded by 7 squares on every side
-constexpr int OH_ENTRIES = OH_W * OH_W * 2; // 16-byte entries: [position][lane half]
-constexpr int BOARD_BYTES = OH_ENTRIES * 16;  // 15488
+// Stage 1 finds the B operand of a tap in two steps: the shifted square's code from a byte
+// mailbox padded by 7 squares on every side (22 x 22, 15 = empty or off the board), then the
+// code's one-hot row from a 16-entry table shared by the workgroup (32 bytes per code: planes
+// 0-7 for lane half 0, planes 8-15 for half 1; plane 15 is 1.0 in every entry).
+constexpr int MB_W = 22;
+constexpr int MB_WORDS = 124;               // 22*22 = 484 bytes, rounded up to whole dwords
 constexpr int XP_W = 10;                    // activation plane padded by 1
 constexpr int POS_BYTES = 64;               // 32 channels bf16
 constexpr int PLANE_BYTES = XP_W * XP_W * POS_BYTES;  // 6400
-static_assert(2 * PLANE_BYTES <= BOARD_BYTES, "the two planes alias the one-hot table");
+constexpr int BOARD_BYTES = 2 * PLANE_BYTES;          // two planes; stage 1 keeps the byte mailbox in the first
+static_assert(MB_WORDS * 4 <= PLANE_BYTES && 2 * 1024 <= PLANE_BYTES, "mailbox and head partial sums alias plane 0");
+#ifndef BF16_WPS
+#define BF16_WPS 2
+#endif
+constexpr int WPS = BF16_WPS;               // waves per SIMD the register budget is set for
 static_assert(BPB <= 16, "the head puts boards on the 16 columns of one MFMA");
 
 struct Lds {
     f32x4 wring[SLOTS][CHUNK][64];                       // shared A-fragment ring
     __attribute__((aligned(16))) unsigned char board[BPB][BOARD_BYTES];
-    f32x4 red[WAVES][64];                                // head: per-wave partial sums
+    u32x4 onehot[16][2];                                 // stage 1: [code][lane half] -> 8 bf16 planes
 };
+
+// Workgroup barrier for LDS hand-offs: every LDS access of this wave has completed; global
+// memory and the LDS-DMA queue are left alone (__syncthreads() would drain them: vmcnt(0)).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Chunk barrier of the weight ring: additionally this wave's share of the chunk about to be read
+// has landed.  The wave's LDS-DMA queue holds, oldest first, its shares of that chunk and of the
+// SLOTS-2 chunks after it; vector-memory operations retire in order, so leaving (SLOTS-2)*SHARE of
+// them outstanding is enough (younger ordinary loads only make the wait stricter).
+__device__ __forceinline__ void ring_barrier() {
+    constexpr int N = (SLOTS - 2) * SHARE;
+    static_assert(N < 64, "vmcnt is a 6-bit counter");
+#ifdef BF16_ABL_NOBAR
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+#else
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+#endif
+}
 
 // Lockstep walk over the A-fragment stream through the LDS ring (see eval_f32.hip).
 struct WStream {
@@ -84,27 +119,38 @@ struct WStream {
     int rd;                // float4 offset of the slot the look-ahead reads from
     f32x4 pre[LA + 1];
 
+    // LDS-DMA: SHARE x 1 KiB straight from L2 into ring slot `slot_off`, lane-linear.  Issued as
+    // inline asm on purpose: the compiler models global_load_lds as a FLAT access that may touch
+    // LDS, and while one is outstanding it turns every LDS wait into lgkmcnt(0), which stalls each
+    // group of MFMAs on the read just issued.  ring_barrier() does the vmcnt bookkeeping instead;
+    // ordinary loads interleaved by the compiler only make its own vmcnt waits stricter
+    // (vector-memory operations retire in order).
     __device__ __forceinline__ void fetch_into(int slot_off) {
+        typedef __attribute__((address_space(3))) f32x4* lds_ptr;
+        const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr)(share + slot_off);
+#ifndef BF16_ABL_NODMA
 #pragma unroll
         for (int i = 0; i < SHARE; ++i)
-            __builtin_amdgcn_global_load_lds(src + i * 64, share + slot_off + i * 64, 16, 0, 0);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                         :: "s"(lds0 + i * 1024), "v"(src + i * 64) : "memory", "m0");
+#endif
         src += CHUNK * 64;
     }
     __device__ __forceinline__ void prime(const f32x4* stream, f32x4* ring_base, int lane, int wave) {
         ring = ring_base + lane;
         share = ring_base + wave * SHARE * 64;
         src = stream + wave * SHARE * 64 + lane;
-        fetch_into(0);
-        fetch_into(CHUNK * 64);
+#pragma unroll
+        for (int i = 0; i < SLOTS - 1; ++i) fetch_into(i * CHUNK * 64);
         rd = (SLOTS - 1) * CHUNK * 64;
     }
     // After the barrier every wave's share of chunk k is in LDS and nobody reads chunk k-1 any
-    // more (its last group went to registers LA groups ago), so its slot takes chunk k+2.
+    // more (its last group went to registers LA groups ago), so its slot takes chunk k+SLOTS-1.
     __device__ __forceinline__ void next_chunk() {
         const int free_slot = rd;
         rd = (rd == (SLOTS - 1) * CHUNK * 64) ? 0 : rd + CHUNK * 64;
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
+        ring_barrier();
         __builtin_amdgcn_sched_barrier(0);
         fetch_into(free_slot);
     }
@@ -117,7 +163,9 @@ struct WStream {
     __device__ __forceinline__ bf16x8 take(int g) {
         const int nx = g + LA;
         if (nx % CHUNK == 0) next_chunk();
+#ifndef BF16_ABL_NOAREAD
         pre[nx % (LA + 1)] = ring[rd + (nx % CHUNK) * 64];
+#endif
         __builtin_amdgcn_sched_barrier(0);
         return __builtin_bit_cast(bf16x8, pre[g % (LA + 1)]);
     }
@@ -135,7 +183,10 @@ __device__ __forceinline__ float pick(int hl, float lo, float hi) { return hl ? 
 // bf16(max(a, 0)), bf16(max(b, 0)) packed low / high: rounding commutes with the clamp, and on
 // the bf16 bit patterns the clamp is a signed 16-bit max with 0.
 __device__ __forceinline__ unsigned pack_relu(float a, float b) {
-    const bf16x2 v = {(__bf16)a, (__bf16)b};
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    // one vector conversion = one v_cvt_pk_bf16_f32 (two scalar casts convert each half separately
+    // and merge with v_perm; inline asm would sit behind an MFMA without the hazard wait states)
+    const bf16x2 v = __builtin_convertvector(f32x2{a, b}, bf16x2);
     s16x2 s = __builtin_bit_cast(s16x2, v);
     s = __builtin_elementwise_max(s, s16x2{0, 0});
     return __builtin_bit_cast(unsigned, s);
@@ -143,6 +194,11 @@ __device__ __forceinline__ unsigned pack_relu(float a, float b) {
 __device__ __forceinline__ float bf16_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xFFFF0000u); }
 
+#ifdef BF_STAMPS
+#define BF_STAMP(i) do { if (lane == 0) stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BF_STAMP(i) ((void)0)
+#endif
 #define BF_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
 __device__ __forceinline__ f32x16 zero16() {
@@ -150,19 +206,22 @@ __device__ __forceinline__ f32x16 zero16() {
 }
 
 // Stage 1, one input conv.  reference: ann_creation_helper.py:211-236 (SAME padding:
-// (k-1)*d in total, floor(/2) before).  ohc: this lane's entry of the one-hot table.
+// (k-1)*d in total, floor(/2) before).  mbc: this lane's square in the byte mailbox; tbl: the one-hot table at this lane's half.
 template <int I, bool DBG>
-__device__ __forceinline__ void input_conv(WStream& ws, const u32x4* ohc, unsigned (&P)[kX1Dwords], int hl, int sq,
-                                           float* dbg_board) {
+__device__ __forceinline__ void input_conv(WStream& ws, const unsigned char* mbc, const u32x4* tbl,
+                                           unsigned (&P)[kX1Dwords], int hl, int sq, float* dbg_board) {
     constexpr InputConv cv = kInputConvs[I];
     constexpr int G0 = input_group_base(I);
     constexpr int ph = ((cv.k - 1) * cv.dh) / 2, pw = ((cv.k - 1) * cv.dw) / 2;
-    u32x4 b[cv.k * cv.k];
+    int code[cv.k * cv.k];
 #pragma unroll
     for (int tap = 0; tap < cv.k * cv.k; ++tap) {
         const int dr = (tap / cv.k) * cv.dh - ph, df = (tap % cv.k) * cv.dw - pw;
-        b[tap] = ohc[(dr * OH_W + df) * 2];
+        code[tap] = mbc[dr * MB_W + df];
     }
+    u32x4 b[cv.k * cv.k];
+#pragma unroll
+    for (int tap = 0; tap < cv.k * cv.k; ++tap) b[tap] = tbl[code[tap] * 2];
     f32x16 acc[cv.tiles];
 #pragma unroll
     for (int tap = 0; tap < cv.k * cv.k; ++tap)
@@ -216,7 +275,7 @@ __device__ __forceinline__ void conv3x3_chunk(WStream& ws, int g0, const unsigne
 }
 
 template <bool DBG>
-__global__ __launch_bounds__(THREADS, 2) void k_eval_bf16(const uint8_t* __restrict__ mailbox, unsigned n_boards,
+__global__ __launch_bounds__(THREADS, WPS) void k_eval_bf16(const uint8_t* __restrict__ mailbox, unsigned n_boards,
                                                            const f32x4* __restrict__ wstream,
                                                            const float* __restrict__ bias,
                                                            const f32x4* __restrict__ headw,
@@ -231,47 +290,55 @@ __global__ __launch_bounds__(THREADS, 2) void k_eval_bf16(const uint8_t* __restr
     const unsigned board_raw = blockIdx.x * BPB + bib;
     const unsigned board = board_raw < n_boards ? board_raw : n_boards - 1;  // padding boards repeat the last one
 
+#ifdef BF_STAMPS
+    long long stamps[8];
+#endif
+    BF_STAMP(0);
     WStream ws;
     ws.prime(wstream, &lds.wring[0][0][0], lane, wave);
 
-    // ---- one-hot table: every entry empty, the 16th plane (half 1, element 7) = 1.0 everywhere ----
+    // ---- byte mailbox (15 everywhere, then the board's codes) and the one-hot table ----------
     unsigned char* region = lds.board[bib];
-    u32x4* oh = reinterpret_cast<u32x4*>(region);
-    for (int e = btid; e < OH_ENTRIES; e += 128) oh[e] = u32x4{0u, 0u, 0u, (e & 1) ? 0x3F800000u : 0u};
+    u32x4* zero_area = reinterpret_cast<u32x4*>(region);
+    if (btid < MB_WORDS) reinterpret_cast<unsigned*>(region)[btid] = 0x0F0F0F0Fu;
+    if (tid < 32) {
+        const unsigned c = tid >> 1, hh = tid & 1, j = c & 7u;
+        const unsigned one = (c != 15u && (c >> 3) == hh) ? (0x3F80u << ((j & 1u) * 16u)) : 0u;
+        u32x4 e = u32x4{0u, 0u, 0u, hh ? 0x3F800000u : 0u};  // plane 15 = 1.0 in every entry
+        e.x |= ((j >> 1) == 0u) ? one : 0u;
+        e.y |= ((j >> 1) == 1u) ? one : 0u;
+        e.z |= ((j >> 1) == 2u) ? one : 0u;
+        e.w |= ((j >> 1) == 3u) ? one : 0u;
+        lds.onehot[c][hh] = e;
+    }
     __syncthreads();
     if (btid < 64) {
         const unsigned v = mailbox[(size_t)board * kMailboxBytes + (btid >> 1)];
         const unsigned c = (btid & 1) ? (v >> 4) : (v & 15u);
-        if (c != 15u) {
-            const unsigned hh = c >> 3, j = c & 7u;
-            const unsigned one = 0x3F80u << ((j & 1u) * 16u);
-            u32x4 e = u32x4{0u, 0u, 0u, hh ? 0x3F800000u : 0u};
-            e.x |= ((j >> 1) == 0u) ? one : 0u;
-            e.y |= ((j >> 1) == 1u) ? one : 0u;
-            e.z |= ((j >> 1) == 2u) ? one : 0u;
-            e.w |= ((j >> 1) == 3u) ? one : 0u;
-            oh[(((btid >> 3) + 7) * OH_W + (btid & 7) + 7) * 2 + hh] = e;
-        }
+        region[((btid >> 3) + 7) * MB_W + (btid & 7) + 7] = (unsigned char)c;
     }
     ws.start();  // its barrier also orders the table writes before stage 1 reads them
 
     float* dbg_board = DBG ? dbg + (size_t)board * kDebugFloatsPerBoard : nullptr;
+    BF_STAMP(1);
 
     // ---- stage 1: input convs -> x1 as 60 packed dwords -------------------------------------
     unsigned P[kX1Dwords];
     {
-        const u32x4* ohc = oh + ((rank + 7) * OH_W + file + 7) * 2 + hl;
-        input_conv<0, DBG>(ws, ohc, P, hl, sq, dbg_board);
-        input_conv<1, DBG>(ws, ohc, P, hl, sq, dbg_board);
-        input_conv<2, DBG>(ws, ohc, P, hl, sq, dbg_board);
-        input_conv<3, DBG>(ws, ohc, P, hl, sq, dbg_board);
-        input_conv<4, DBG>(ws, ohc, P, hl, sq, dbg_board);
-        input_conv<5, DBG>(ws, ohc, P, hl, sq, dbg_board);
-        input_conv<6, DBG>(ws, ohc, P, hl, sq, dbg_board);
-        input_conv<7, DBG>(ws, ohc, P, hl, sq, dbg_board);
-        input_conv<8, DBG>(ws, ohc, P, hl, sq, dbg_board);
+        const unsigned char* mbc = region + (rank + 7) * MB_W + file + 7;
+        const u32x4* tbl = &lds.onehot[0][hl];
+        input_conv<0, DBG>(ws, mbc, tbl, P, hl, sq, dbg_board);
+        input_conv<1, DBG>(ws, mbc, tbl, P, hl, sq, dbg_board);
+        input_conv<2, DBG>(ws, mbc, tbl, P, hl, sq, dbg_board);
+        input_conv<3, DBG>(ws, mbc, tbl, P, hl, sq, dbg_board);
+        input_conv<4, DBG>(ws, mbc, tbl, P, hl, sq, dbg_board);
+        input_conv<5, DBG>(ws, mbc, tbl, P, hl, sq, dbg_board);
+        input_conv<6, DBG>(ws, mbc, tbl, P, hl, sq, dbg_board);
+        input_conv<7, DBG>(ws, mbc, tbl, P, hl, sq, dbg_board);
+        input_conv<8, DBG>(ws, mbc, tbl, P, hl, sq, dbg_board);
     }
 
+    BF_STAMP(2);
     // ---- stage 2: 1x1 236->512 (+ReLU) chained into 1x1 512->128 ---------------------------
     f32x16 acc3[4];
 #pragma unroll
@@ -283,9 +350,9 @@ __global__ __launch_bounds__(THREADS, 2) void k_eval_bf16(const uint8_t* __restr
 #pragma unroll 1
     for (int it = 0; it < kC2Tiles / C2_UNROLL; ++it) {
         if (it == 1) {
-            // Every wave is past stage 1 (at least one chunk barrier lies behind us): the one-hot
-            // table is dead, its space becomes the two zero-haloed activation planes.
-            for (int i = btid; i < 2 * PLANE_BYTES / 16; i += 128) oh[i] = u32x4{0u, 0u, 0u, 0u};
+            // Every wave is past stage 1 (at least one chunk barrier lies behind us): the byte
+            // mailbox is dead, its space becomes the two zero-haloed activation planes.
+            for (int i = btid; i < 2 * PLANE_BYTES / 16; i += 128) zero_area[i] = u32x4{0u, 0u, 0u, 0u};
         }
 #pragma unroll
         for (int u = 0; u < C2_UNROLL; ++u) {
@@ -322,6 +389,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_eval_bf16(const uint8_t* __restr
             }
     }
 
+    BF_STAMP(3);
     // ---- stages 3 and 4: the six 3x3 layers through LDS -----------------------------------
     const int R0 = rank + 1;
     const int woff = (R0 * XP_W + file + 1) * POS_BYTES;   // this lane's square
@@ -339,9 +407,10 @@ __global__ __launch_bounds__(THREADS, 2) void k_eval_bf16(const uint8_t* __restr
     for (int q = 0; q < 4; ++q) {
         unsigned char* plane = region + (q & 1) * PLANE_BYTES;
         write_tile(plane + woff, R0, hl, acc3[q]);
-        __syncthreads();
+        lds_barrier();
         conv3x3_chunk(ws, kConvBase + q * 18, plane, raddr, acc);
     }
+    BF_STAMP(4);
 #pragma unroll
     for (int layer = 0; layer < 5; ++layer) {
         unsigned char* plane = region + (layer & 1) * PLANE_BYTES;
@@ -354,15 +423,17 @@ __global__ __launch_bounds__(THREADS, 2) void k_eval_bf16(const uint8_t* __restr
                 dbg_board[64 * (236 + 128 + 32 * layer) + rowmap(t + 1, hl) * 64 + sq] = bf16_hi(p);
             }
         }
-        __syncthreads();
+        lds_barrier();
         const float* bl = bias + kBiasX4 + 32 * (layer + 1);
 #pragma unroll
         for (int t = 0; t < 16; ++t) acc[t] = pick(hl, bl[rowmap(t, 0)], bl[rowmap(t, 1)]);
         conv3x3_chunk(ws, kConvBase + kConv4Groups + layer * 18, plane, raddr, acc);
     }
 
+    BF_STAMP(5);
     // ---- stage 5: 8x8 valid conv (2048 -> 16) across the workgroup's boards, ReLU, logit ------
     // x9 goes to plane 1 (layer 4 read plane 0; plane 1 was last read one barrier earlier).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring's look-ahead DMA must not outlive the workgroup
     write_tile(region + PLANE_BYTES + woff, R0, hl, acc);
     if (DBG) {
 #pragma unroll
@@ -390,7 +461,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_eval_bf16(const uint8_t* __restr
             hacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ha[i]), __builtin_bit_cast(bf16x8, b),
                                                            hacc, 0, 0, 0);
         }
-        lds.red[wave][lane] = hacc;
+        // partial sums go to plane 0 of this wave's board (last read before the barrier above)
+        reinterpret_cast<f32x4*>(region + half * 1024)[lane] = hacc;
     }
     __syncthreads();
     if (tid < 16 * BPB) {
@@ -398,7 +470,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_eval_bf16(const uint8_t* __restr
         // D[row = co][col = b] sits in lane b + 16*(co>>2), register co&3
         float s = 0.0f;
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) s += reinterpret_cast<const float*>(&lds.red[w][b + 16 * (co >> 2)])[co & 3];
+        for (int w = 0; w < WAVES; ++w)
+            s += reinterpret_cast<const float*>(lds.board[w >> 1] + (w & 1) * 1024)[(b + 16 * (co >> 2)) * 4 + (co & 3)];
         const float y = fmaxf(s + bias[kBiasX10 + co], 0.0f);
         const unsigned out_raw = blockIdx.x * BPB + b;
         if (DBG && out_raw < n_boards) dbg[(size_t)out_raw * kDebugFloatsPerBoard + 64 * (236 + 128 + 32 * 6) + co] = y;
@@ -409,6 +482,13 @@ __global__ __launch_bounds__(THREADS, 2) void k_eval_bf16(const uint8_t* __restr
         v += __shfl_xor(v, 8);
         if (co == 0 && out_raw < n_boards) scores[out_raw] = v;
     }
+#ifdef BF_STAMPS
+    BF_STAMP(6);
+    if (!DBG && dbg && lane == 0) {
+        long long* out = reinterpret_cast<long long*>(dbg) + ((size_t)blockIdx.x * WAVES + wave) * 8;
+        for (int i = 0; i < 7; ++i) out[i] = stamps[i];
+    }
+#endif
 }
 
 }  // namespace
@@ -430,7 +510,11 @@ hipError_t b16::launch(const uint8_t* d_mailbox, size_t n, const unsigned char* 
     const float* bias = reinterpret_cast<const float*>(d_image + kOffBias);
     const f32x4* head = reinterpret_cast<const f32x4*>(d_image + kOffHead);
     const unsigned blocks = (unsigned)((n + BPB - 1) / BPB);
+#ifdef BF_STAMPS
+    if (false)
+#else
     if (d_debug)
+#endif
         hipLaunchKernelGGL(k_eval_bf16<true>, dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, (unsigned)n, ws, bias,
                            head, d_scores, d_debug);
     else

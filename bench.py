@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 
 BATCH = 65536
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak (not the 2:1-sparsity figure)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -74,6 +75,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32 = BASELINE configs[1] (the headline); bf16 = the configs[2] kernel at the same batch")
     args = ap.parse_args()
 
     import torch
@@ -91,7 +94,9 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     n = args.batch
-    ctx = ops.DeviceContext(weights.make_weights(seed=1234, bn="perturbed"), device=local_rank)
+    ctx = ops.DeviceContext(weights.make_weights(seed=1234, bn="perturbed"), device=local_rank, dtype=args.dtype)
+    bf16 = args.dtype == "bf16"
+    peak_tflops = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
     structs = positions.to_compact(positions.random_structs(n, seed=1000 + rank))
     recs = ops.records_to_tensor(structs, dev)
     gathered = [torch.empty(n, dtype=torch.float32, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
@@ -160,15 +165,15 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: value CNN (9 dilated input convs + tower + logit), "
-                                   "random init, batch %d per GPU, fp32, from packed node records resident in HBM "
-                                   "(fused ingest + conv + head)" % n,
+                                   "random init, batch %d per GPU, %s, from packed node records resident in HBM "
+                                   "(fused ingest + conv + head)" % (n, "bf16 operands / fp32 sums (configs[2] kernel)" if bf16 else "fp32"),
                        "per_gpu_batch": n, "global_batch": world * n,
                        "parallelism": "independent shards per GPU" + (", RCCL gather of scores to rank 0" if world > 1 else "")},
-            "roofline": {"bound": "mfma", "kernel": "k_eval_f32", "achieved": achieved_tflops,
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_F32_MFMA_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": "k_eval_bf16" if bf16 else "k_eval_f32", "achieved": achieved_tflops,
+                         "peak": peak_tflops, "unit": "TFLOP/s", "frac": achieved_tflops / peak_tflops,
                          "traffic": None, "kernel_ms": kernel_ms,
                          "flops_per_board": spec.FLOPS_PER_BOARD},
             "encode_roofline": {"bound": "hbm", "kernel": "k_to_planes<StructSrc>", "achieved": enc_gbs,
