@@ -23,15 +23,18 @@ dbg = torch.zeros((n, lib.bf_debug_floats_per_board()), device="cuda")
 for _ in range(3):
     lib.bf_eval_mailbox_debug(ctx, mb.data_ptr(), n, scores.data_ptr(), dbg.data_ptr(), st)
 torch.cuda.synchronize()
-waves = 2 * bpb
-raw = dbg.view(-1)[: (n // bpb) * waves * 8 * 2].cpu().numpy().view(np.int64).reshape(n // bpb, waves, 8)
+waves = bpb
+raw = dbg.view(-1)[: (n // bpb) * waves * 16 * 2].cpu().numpy().view(np.int64).reshape(n // bpb, waves, 16)
 t = raw[:, :, :7]
 d = np.diff(t, axis=2)
 names = ["setup", "stage1", "gemm", "conv4", "conv5-9", "head"]
-ideal = [0, 80 * 32, 16 * 23 * 32, 72 * 32, 90 * 32, 0]
+ideal = [0, 160 * 32, 16 * 46 * 32, 144 * 32, 180 * 32, 0]
 life = t[:, :, 6] - t[:, :, 0]
 print("blocks", n // bpb, "wave life median %.0f  own MFMA cycles %d" % (np.median(life), sum(ideal)))
 for i, nm in enumerate(names):
     print("%-8s median %9.0f  p10 %9.0f  p90 %9.0f   own MFMA cycles %7d" % (nm, np.median(d[:, :, i]), np.percentile(d[:, :, i], 10), np.percentile(d[:, :, i], 90), ideal[i]))
 span = t[:, :, 6].max() - t[:, :, 0].min()
 print("kernel span (stamp ticks)", span, " sum of wave lives / span = average waves in flight %.1f" % (life.sum() / span))
+ph = np.diff(raw[:, :, 8:14], axis=2)
+for i, nm in enumerate(["A G1 t0 (480)", "B G1 t1 (480)", "C G2 t0 (256)", "D G2 t1 (256)", "next tile (1472)"]):
+    print("%-18s median %7.0f p10 %7.0f p90 %7.0f" % (nm, np.median(ph[:, :, i]), np.percentile(ph[:, :, i], 10), np.percentile(ph[:, :, i], 90)))
