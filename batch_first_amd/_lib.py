@@ -46,6 +46,14 @@ SIGNATURES = {
     "bf_host_encode_wire": (_int, [_vp, _sz, _vp, _sz, _vp, _vp, _c.POINTER(_sz), _c.POINTER(_sz)]),
     "bf_packed_floats": (_sz, []),
     "bf_pack_weights": (_int, [_vp, _sz, _vp, _sz]),
+    "bf_pack_policy_weights": (_int, [_vp, _sz, _vp, _sz]),
+    "bf_ctx_set_policy": (_int, [_vp, _vp, _sz]),
+    "bf_policy_features_wire": (_int, [_vp, _vp, _sz, _vp, _sz, _vp, _vp]),
+    "bf_policy_features_structs": (_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
+    "bf_policy_scores": (_int, [_vp, _vp, _sz, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "bf_policy_check": (_int, [_vp, _vp]),
+    "bf_policy_start_wire_host": (_int, [_vp, _vp, _sz, _vp, _sz]),
+    "bf_policy_finish_host": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _vp]),
     "bf_packed_bf16_bytes": (_sz, []),
     "bf_pack_weights_bf16": (_int, [_vp, _sz, _vp, _sz]),
     # debugging aids, not part of the public header

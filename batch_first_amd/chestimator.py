@@ -18,6 +18,37 @@ import numpy as np
 from . import _lib, weights as _weights
 
 
+def _as_policy_blob(weights):
+    if isinstance(weights, (str, os.PathLike)):
+        blob = np.load(os.fspath(weights))
+    elif isinstance(weights, dict):
+        blob = _weights.to_policy_blob(weights)
+    else:
+        blob = np.asarray(weights)
+    blob = np.ascontiguousarray(blob, dtype=np.float32).ravel()
+    if blob.size != _weights.policy_blob_size():
+        raise ValueError("policy weight blob has %d floats, expected %d" % (blob.size, _weights.policy_blob_size()))
+    return blob
+
+
+def _wire_arrays(piece_filters, occupied_bbs):
+    """The feed arrays as raw bytes / bit patterns (the TF placeholders are int32 / int64 fed with
+    uint8 / uint64, ann_creation_helper.py:50-51; compress_square_array returns a strided view, :19)."""
+    pf = np.ascontiguousarray(piece_filters)
+    if pf.dtype != np.uint8:
+        if pf.size and (pf.min() < 0 or pf.max() > 255):
+            raise ValueError("piece_filters values must be bytes (0..255)")
+        pf = pf.astype(np.uint8)
+    occ = np.ascontiguousarray(occupied_bbs)
+    if occ.dtype == np.int64:
+        occ = occ.view(np.uint64)
+    elif occ.dtype != np.uint64:
+        occ = occ.astype(np.uint64)
+    if pf.ndim != 1 or occ.ndim != 1:
+        raise ValueError("piece_filters and occupied_bbs must be one-dimensional")
+    return pf, occ
+
+
 def _as_blob(weights):
     if isinstance(weights, (str, os.PathLike)):
         path = os.fspath(weights)
@@ -48,26 +79,14 @@ class BoardPredictor:
         self._ctx = ctx
         self.dtype = "bf16" if _lib.precision_code(dtype) == _lib.BF_PRECISION_BF16 else "f32"
         self._closed = False
+        self.has_policy = False
         self._close_lock = threading.Lock()
         self.device = int(device)
 
     # -- the reference's callable ---------------------------------------------------------
     def __call__(self, piece_filters, occupied_bbs):
         ctx = self._handle()
-        # to_compress[::2] in compress_square_array (numba_negamax_zero_window.py:19) is a strided view
-        pf = np.ascontiguousarray(piece_filters)
-        if pf.dtype != np.uint8:
-            # the TF placeholder is int32 "given as an array of uint8s" (ann_creation_helper.py:50)
-            if pf.size and (pf.min() < 0 or pf.max() > 255):
-                raise ValueError("piece_filters values must be bytes (0..255)")
-            pf = pf.astype(np.uint8)
-        occ = np.ascontiguousarray(occupied_bbs)
-        if occ.dtype == np.int64:
-            occ = occ.view(np.uint64)  # placeholder is int64 fed with uint64 bits (:51)
-        elif occ.dtype != np.uint64:
-            occ = occ.astype(np.uint64)
-        if pf.ndim != 1 or occ.ndim != 1:
-            raise ValueError("piece_filters and occupied_bbs must be one-dimensional")
+        pf, occ = _wire_arrays(piece_filters, occupied_bbs)
         n = occ.size
         scores = np.empty(n, dtype=np.float32)
         if n == 0:
@@ -102,6 +121,36 @@ class BoardPredictor:
             raise _lib.BatchFirstError("evaluated %d boards, expected %d" % (done.value, count))
         return scores
 
+    # -- the move-scoring network ------------------------------------------------------------
+    def set_policy(self, policy_weights):
+        blob = _as_policy_blob(policy_weights)
+        _lib.check(self._lib.bf_ctx_set_policy(self._handle(), blob.ctypes.data, blob.size))
+        self.has_policy = True
+
+    def start_move_prediction(self, piece_filters, occupied_bbs):
+        """chestimator.py:40-46: start stage 1 on the boards, return the closure that takes
+        ``move_info = [from_squares, move_filters, moves_per_board]`` and returns float32 scores."""
+        ctx = self._handle()
+        pf, occ = _wire_arrays(piece_filters, occupied_bbs)
+        n = occ.size
+        _lib.check(self._lib.bf_policy_start_wire_host(ctx, pf.ctypes.data, pf.size, occ.ctypes.data, n))
+
+        def finish(move_info):
+            frm, flt, per = (np.ascontiguousarray(a) for a in move_info)
+            for name, a in (("from_squares", frm), ("move_filters", flt), ("moves_per_board", per)):
+                if a.dtype != np.uint8:   # uint8 placeholders, move_evaluation_ann.py:244-246
+                    if a.size and (a.min() < 0 or a.max() > 255):
+                        raise ValueError("%s values must fit uint8" % name)
+            frm, flt, per = frm.astype(np.uint8, copy=False), flt.astype(np.uint8, copy=False), per.astype(np.uint8, copy=False)
+            if frm.shape != flt.shape or frm.ndim != 1 or per.ndim != 1:
+                raise ValueError("from_squares and move_filters must be one-dimensional and equally long")
+            scores = np.empty(frm.size, dtype=np.float32)
+            _lib.check(self._lib.bf_policy_finish_host(self._handle(), frm.ctypes.data, flt.ctypes.data, per.ctypes.data,
+                                                       per.size, frm.size, scores.ctypes.data))
+            return scores
+
+        return finish
+
     def _handle(self):
         if self._closed:
             raise RuntimeError("the evaluator has been closed")
@@ -121,21 +170,26 @@ class BoardPredictor:
             pass
 
 
-def get_inference_functions(weights, session_gpu_memory=.4, device=0, dtype="f32"):
+def get_inference_functions(weights, session_gpu_memory=.4, device=0, dtype="f32", policy_weights=None):
     """(board_predictor, start_move_prediction, closer_fn), as batch_first/chestimator.py:51-74.
 
     ``weights`` replaces ``graphdef_filename``: a ``.npy``/``.npz`` file holding the canonical
     blob (weights.to_blob), the blob itself, or a weights dict.  ``session_gpu_memory`` is
     accepted for call compatibility and ignored (TensorFlow's allocator fraction has no
     counterpart here).  ``dtype``: "f32" (the parity path) or "bf16" (bf16 operands, float32 sums;
-    include/batchfirst.h, BF_PRECISION_BF16).
+    include/batchfirst.h, BF_PRECISION_BF16).  ``policy_weights``: the move-scoring network's blob
+    (weights.to_policy_blob), file or dict; it always runs in float32.
     """
     del session_gpu_memory
     board_predictor = BoardPredictor(weights, device=device, dtype=dtype)
+    if policy_weights is not None:
+        board_predictor.set_policy(policy_weights)
 
     def start_move_prediction(*board_inputs):
-        # The policy network (move_evaluation_ann.py) is outside this build's scope (SURVEY.md 8(f) #2).
-        raise NotImplementedError("the move-scoring network is not part of this build")
+        if not board_predictor.has_policy:
+            # the reference's frozen graph holds both networks; here the policy blob is optional
+            raise NotImplementedError("no move-scoring network was loaded (policy_weights=...)")
+        return board_predictor.start_move_prediction(*board_inputs)
 
     def closer_fn():
         board_predictor.close()

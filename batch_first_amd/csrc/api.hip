@@ -18,13 +18,12 @@
         if (e_ != hipSuccess) return bf::fail(BF_E_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
-struct bf_ctx {
-    int device = 0;
-    int precision = BF_PRECISION_F32;
-    float* d_packed = nullptr;            // fp32 image (bf_layout.h) when precision == BF_PRECISION_F32
-    unsigned char* d_image16 = nullptr;   // bf16 image (bf_layout_bf16.h) when precision == BF_PRECISION_BF16
-    int* d_err = nullptr;
-    // scratch grown on demand; guarded by `mu` (calls on one context are serialised)
+// Scratch, staging and stream of one evaluation pipeline.  The value network and the move-scoring
+// network each own one, so that the search's two worker threads (numba_negamax_zero_window.py:178,
+// :199) can have one call of each in flight at the same time.
+struct Lane {
+    int* d_err = nullptr;            // sticky malformed-input flag
+    // scratch grown on demand; guarded by `mu` (calls on one lane are serialised)
     std::mutex mu;
     size_t cap_boards = 0;
     unsigned* d_local_off = nullptr;
@@ -38,6 +37,20 @@ struct bf_ctx {
     size_t cap_scores = 0;
     float* h_scores = nullptr;       // pinned
     float* d_scores = nullptr;
+};
+
+struct bf_ctx : Lane {               // the base is the value network's lane
+    int device = 0;
+    int precision = BF_PRECISION_F32;
+    float* d_packed = nullptr;            // fp32 image (bf_layout.h) when precision == BF_PRECISION_F32
+    unsigned char* d_image16 = nullptr;   // bf16 image (bf_layout_bf16.h) when precision == BF_PRECISION_BF16
+    // move-scoring network (bf_ctx_set_policy)
+    Lane policy;
+    float* d_policy_packed = nullptr;
+    size_t cap_x9_boards = 0;
+    float* d_x9 = nullptr;                // [boards][32][64] features of the batch in flight
+    size_t policy_boards = 0;             // boards of the started, not yet finished, prediction
+    bool policy_started = false;
 };
 
 namespace {
@@ -54,7 +67,7 @@ struct DeviceGuard {
     }
 };
 
-int ensure_boards(bf_ctx* c, size_t n) {
+int ensure_boards(Lane* c, size_t n) {
     if (n <= c->cap_boards) return BF_OK;
     size_t cap = c->cap_boards ? c->cap_boards : 4096;
     while (cap < n) cap *= 2;
@@ -69,7 +82,7 @@ int ensure_boards(bf_ctx* c, size_t n) {
     return BF_OK;
 }
 
-int ensure_staging(bf_ctx* c, size_t in_bytes, size_t n_scores) {
+int ensure_staging(Lane* c, size_t in_bytes, size_t n_scores) {
     if (in_bytes > c->cap_in_bytes) {
         size_t cap = c->cap_in_bytes ? c->cap_in_bytes : (1u << 20);
         while (cap < in_bytes) cap *= 2;
@@ -99,15 +112,16 @@ hipError_t launch_eval(bf_ctx* c, const uint8_t* d_mailbox, size_t n, float* d_s
     return bf::launch_eval_f32(d_mailbox, n, c->d_packed, d_scores, d_debug, s);
 }
 
-bf::Workspace workspace(bf_ctx* c) { return bf::Workspace{c->d_local_off, c->d_block_total, c->d_err}; }
+bf::Workspace workspace(Lane* c) { return bf::Workspace{c->d_local_off, c->d_block_total, c->d_err}; }
 
-int read_err_flag(bf_ctx* c, hipStream_t s) {
+int read_err_flag(Lane* c, hipStream_t s) {
     int flag = 0;
     BF_HIP(hipMemcpyAsync(&flag, c->d_err, sizeof flag, hipMemcpyDeviceToHost, s));
     BF_HIP(hipStreamSynchronize(s));
     if (flag) {
         BF_HIP(hipMemsetAsync(c->d_err, 0, sizeof(int), s));
         BF_HIP(hipStreamSynchronize(s));
+        if (flag & 4) return bf::fail(BF_E_FORMAT, "move input: board index, from-square or move filter out of range");
         if (flag & 2) return bf::fail(BF_E_FORMAT, "wire input holds code 15, which is not a piece code");
         return bf::fail(BF_E_FORMAT, "wire input: piece_filters length does not match the popcounts of occupied_bbs");
     }
@@ -173,10 +187,12 @@ extern "C" int bf_ctx_create_ex(bf_ctx** out, int device, const float* h_weights
         if (hipMemcpy(c->d_packed, packed.data(), bf::kPackedFloats * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
             return bail(bf::fail(BF_E_HIP, "bf_ctx_create: weight upload failed"));
     }
-    if (hipMalloc(&c->d_err, 256) != hipSuccess || hipMemset(c->d_err, 0, 256) != hipSuccess)
-        return bail(bf::fail(BF_E_HIP, "bf_ctx_create: flag allocation failed"));
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
-        return bail(bf::fail(BF_E_HIP, "bf_ctx_create: stream creation failed"));
+    for (Lane* lane : {static_cast<Lane*>(c), &c->policy}) {
+        if (hipMalloc(&lane->d_err, 256) != hipSuccess || hipMemset(lane->d_err, 0, 256) != hipSuccess)
+            return bail(bf::fail(BF_E_HIP, "bf_ctx_create: flag allocation failed"));
+        if (hipStreamCreateWithFlags(&lane->stream, hipStreamNonBlocking) != hipSuccess)
+            return bail(bf::fail(BF_E_HIP, "bf_ctx_create: stream creation failed"));
+    }
     *out = c;
     return BF_OK;
 }
@@ -184,20 +200,24 @@ extern "C" int bf_ctx_create_ex(bf_ctx** out, int device, const float* h_weights
 extern "C" void bf_ctx_destroy(bf_ctx* c) {
     if (!c) return;
     DeviceGuard guard(c->device);
-    if (c->stream) {
-        (void)hipStreamSynchronize(c->stream);
-        (void)hipStreamDestroy(c->stream);
+    for (Lane* lane : {static_cast<Lane*>(c), &c->policy}) {
+        if (lane->stream) {
+            (void)hipStreamSynchronize(lane->stream);
+            (void)hipStreamDestroy(lane->stream);
+        }
+        if (lane->d_err) (void)hipFree(lane->d_err);
+        if (lane->d_local_off) (void)hipFree(lane->d_local_off);
+        if (lane->d_block_total) (void)hipFree(lane->d_block_total);
+        if (lane->d_mailbox) (void)hipFree(lane->d_mailbox);
+        if (lane->h_in) (void)hipHostFree(lane->h_in);
+        if (lane->d_in) (void)hipFree(lane->d_in);
+        if (lane->h_scores) (void)hipHostFree(lane->h_scores);
+        if (lane->d_scores) (void)hipFree(lane->d_scores);
     }
     if (c->d_packed) (void)hipFree(c->d_packed);
     if (c->d_image16) (void)hipFree(c->d_image16);
-    if (c->d_err) (void)hipFree(c->d_err);
-    if (c->d_local_off) (void)hipFree(c->d_local_off);
-    if (c->d_block_total) (void)hipFree(c->d_block_total);
-    if (c->d_mailbox) (void)hipFree(c->d_mailbox);
-    if (c->h_in) (void)hipHostFree(c->h_in);
-    if (c->d_in) (void)hipFree(c->d_in);
-    if (c->h_scores) (void)hipHostFree(c->h_scores);
-    if (c->d_scores) (void)hipFree(c->d_scores);
+    if (c->d_policy_packed) (void)hipFree(c->d_policy_packed);
+    if (c->d_x9) (void)hipFree(c->d_x9);
     delete c;
 }
 
@@ -368,5 +388,166 @@ extern "C" int bf_eval_structs_host(bf_ctx* c, const void* h_structs, size_t str
     BF_HIP(hipStreamSynchronize(c->stream));
     std::memcpy(h_scores, c->h_scores, m * sizeof(float));
     if (n_scored) *n_scored = m;
+    return BF_OK;
+}
+
+// ---- the move-scoring network ---------------------------------------------------------------
+
+namespace {
+
+int check_policy(const bf_ctx* c, size_t n, const char* who) {
+    if (int r = check_common(c, n, who)) return r;
+    if (!c->d_policy_packed) return bf::fail(BF_E_ARG, "%s: no move-scoring network loaded (bf_ctx_set_policy)", who);
+    return BF_OK;
+}
+
+int ensure_x9(bf_ctx* c, size_t n) {
+    if (n <= c->cap_x9_boards) return BF_OK;
+    size_t cap = c->cap_x9_boards ? c->cap_x9_boards : 1024;
+    while (cap < n) cap *= 2;
+    if (c->d_x9) (void)hipFree(c->d_x9);
+    c->d_x9 = nullptr; c->cap_x9_boards = 0;
+    BF_HIP(hipMalloc(&c->d_x9, cap * BF_POLICY_FEATURES_PER_BOARD * sizeof(float)));
+    c->cap_x9_boards = cap;
+    return BF_OK;
+}
+
+}  // namespace
+
+extern "C" int bf_ctx_set_policy(bf_ctx* c, const float* h_weights, size_t n_floats) {
+    if (!c || !h_weights) return bf::fail(BF_E_ARG, "bf_ctx_set_policy: null pointer");
+    if (n_floats != bf::kPolicyWeightFloats)
+        return bf::fail(BF_E_ARG, "bf_ctx_set_policy: expected %zu weight floats, got %zu", bf::kPolicyWeightFloats, n_floats);
+    DeviceGuard guard(c->device);
+    std::lock_guard<std::mutex> lock(c->policy.mu);
+    std::vector<float> packed(bf::kPackedFloats);
+    bf::pack_weights(h_weights, packed.data(), true);
+    if (!c->d_policy_packed) BF_HIP(hipMalloc(&c->d_policy_packed, bf::kPackedFloats * sizeof(float)));
+    BF_HIP(hipMemcpy(c->d_policy_packed, packed.data(), bf::kPackedFloats * sizeof(float), hipMemcpyHostToDevice));
+    c->policy_started = false;
+    return BF_OK;
+}
+
+extern "C" int bf_policy_features_wire(bf_ctx* c, const uint8_t* d_pf, size_t n_bytes, const uint64_t* d_occ, size_t n,
+                                       float* d_x9, void* stream) {
+    if (int r = check_policy(c, n, "bf_policy_features_wire")) return r;
+    if (n == 0) return BF_OK;
+    if (!d_occ || !d_x9 || (!d_pf && n_bytes)) return bf::fail(BF_E_ARG, "bf_policy_features_wire: null pointer");
+    DeviceGuard guard(c->device);
+    std::lock_guard<std::mutex> lock(c->policy.mu);
+    if (int r = ensure_boards(&c->policy, n)) return r;
+    BF_HIP(bf::launch_mailbox_from_wire(d_pf, n_bytes, d_occ, n, workspace(&c->policy), c->policy.d_mailbox, (hipStream_t)stream));
+    BF_HIP(bf::launch_policy_features_f32(c->policy.d_mailbox, n, c->d_policy_packed, d_x9, (hipStream_t)stream));
+    return BF_OK;
+}
+
+extern "C" int bf_policy_features_structs(bf_ctx* c, const void* d_structs, size_t stride, size_t n, float* d_x9,
+                                          void* stream) {
+    if (int r = check_policy(c, n, "bf_policy_features_structs")) return r;
+    if (n == 0) return BF_OK;
+    if (!d_structs || !d_x9) return bf::fail(BF_E_ARG, "bf_policy_features_structs: null pointer");
+    if (stride < BF_NODE_EVAL_BYTES) return bf::fail(BF_E_ARG, "bf_policy_features_structs: stride %zu < 82", stride);
+    DeviceGuard guard(c->device);
+    std::lock_guard<std::mutex> lock(c->policy.mu);
+    if (int r = ensure_boards(&c->policy, n)) return r;
+    BF_HIP(bf::launch_mailbox_from_structs(d_structs, stride, n, c->policy.d_mailbox, (hipStream_t)stream));
+    BF_HIP(bf::launch_policy_features_f32(c->policy.d_mailbox, n, c->d_policy_packed, d_x9, (hipStream_t)stream));
+    return BF_OK;
+}
+
+extern "C" int bf_policy_scores(bf_ctx* c, const float* d_x9, size_t n_boards, const uint32_t* d_board_index,
+                                const uint8_t* d_from, const uint8_t* d_filter, size_t n_moves, float* d_scores,
+                                void* stream) {
+    if (int r = check_policy(c, n_boards, "bf_policy_scores")) return r;
+    if (n_moves == 0) return BF_OK;
+    if (n_boards == 0) return bf::fail(BF_E_ARG, "bf_policy_scores: moves given without boards");
+    if (n_moves > ((size_t)1 << 31)) return bf::fail(BF_E_ARG, "bf_policy_scores: %zu moves exceeds the limit of 2^31", n_moves);
+    if (!d_x9 || !d_board_index || !d_from || !d_filter || !d_scores) return bf::fail(BF_E_ARG, "bf_policy_scores: null pointer");
+    DeviceGuard guard(c->device);
+    BF_HIP(bf::launch_policy_scores(d_x9, c->d_policy_packed, d_board_index, d_from, d_filter, n_moves, n_boards,
+                                    c->policy.d_err, d_scores, (hipStream_t)stream));
+    return BF_OK;
+}
+
+extern "C" int bf_policy_check(bf_ctx* c, void* stream) {
+    if (!c) return bf::fail(BF_E_ARG, "bf_policy_check: null context");
+    DeviceGuard guard(c->device);
+    return read_err_flag(&c->policy, (hipStream_t)stream);
+}
+
+extern "C" int bf_policy_start_wire_host(bf_ctx* c, const uint8_t* h_pf, size_t n_bytes, const uint64_t* h_occ, size_t n) {
+    if (int r = check_policy(c, n, "bf_policy_start_wire_host")) return r;
+    if (n && (!h_occ || (!h_pf && n_bytes))) return bf::fail(BF_E_ARG, "bf_policy_start_wire_host: null pointer");
+    size_t total = 0;
+    for (size_t i = 0; i < n; ++i) total += (size_t)__builtin_popcountll(h_occ[i]);
+    if ((total + 1) / 2 != n_bytes)
+        return bf::fail(BF_E_FORMAT, "bf_policy_start_wire_host: %zu piece_filters bytes, but the masks select %zu codes (%zu bytes)",
+                        n_bytes, total, (total + 1) / 2);
+    DeviceGuard guard(c->device);
+    Lane* L = &c->policy;
+    std::lock_guard<std::mutex> lock(L->mu);
+    c->policy_started = false;
+    if (n) {
+        // buffers are reused (and may be regrown): whatever an abandoned prediction left running is drained
+        BF_HIP(hipStreamSynchronize(L->stream));
+        if (int r = ensure_boards(L, n)) return r;
+        if (int r = ensure_x9(c, n)) return r;
+        const size_t occ_bytes = n * sizeof(uint64_t);
+        const size_t pf_off = (occ_bytes + 15) & ~(size_t)15;
+        if (int r = ensure_staging(L, pf_off + n_bytes + 16, 1)) return r;
+        std::memcpy(L->h_in, h_occ, occ_bytes);
+        if (n_bytes) std::memcpy(L->h_in + pf_off, h_pf, n_bytes);
+        BF_HIP(hipMemcpyAsync(L->d_in, L->h_in, pf_off + n_bytes, hipMemcpyHostToDevice, L->stream));
+        BF_HIP(bf::launch_mailbox_from_wire(L->d_in + pf_off, n_bytes, reinterpret_cast<const uint64_t*>(L->d_in), n,
+                                            workspace(L), L->d_mailbox, L->stream));
+        BF_HIP(bf::launch_policy_features_f32(L->d_mailbox, n, c->d_policy_packed, c->d_x9, L->stream));
+    }
+    c->policy_boards = n;
+    c->policy_started = true;
+    return BF_OK;   // the GPU works on while the caller generates the moves to score
+}
+
+extern "C" int bf_policy_finish_host(bf_ctx* c, const uint8_t* h_from, const uint8_t* h_filter,
+                                     const uint8_t* h_moves_per_board, size_t n_boards, size_t n_moves, float* h_scores) {
+    if (int r = check_policy(c, n_boards, "bf_policy_finish_host")) return r;
+    DeviceGuard guard(c->device);
+    Lane* L = &c->policy;
+    std::lock_guard<std::mutex> lock(L->mu);
+    if (!c->policy_started) return bf::fail(BF_E_ARG, "bf_policy_finish_host: no prediction was started");
+    c->policy_started = false;
+    if (n_boards != c->policy_boards)
+        return bf::fail(BF_E_ARG, "bf_policy_finish_host: %zu boards, but the prediction was started with %zu", n_boards, c->policy_boards);
+    if (n_moves && (!h_from || !h_filter || !h_moves_per_board || !h_scores))
+        return bf::fail(BF_E_ARG, "bf_policy_finish_host: null pointer");
+    size_t total = 0;
+    for (size_t b = 0; b < n_boards; ++b) total += h_moves_per_board[b];
+    if (total != n_moves)
+        return bf::fail(BF_E_FORMAT, "bf_policy_finish_host: moves_per_board sums to %zu, but %zu moves were given", total, n_moves);
+    for (size_t m = 0; m < n_moves; ++m)
+        if (h_from[m] >= 64 || h_filter[m] >= BF_POLICY_FILTERS)
+            return bf::fail(BF_E_FORMAT, "bf_policy_finish_host: move %zu has from-square %u, filter %u", m, h_from[m], h_filter[m]);
+    if (n_moves == 0) {
+        BF_HIP(hipStreamSynchronize(L->stream));
+        return read_err_flag(L, L->stream);
+    }
+    // staging: board index u32[n_moves] | from u8[n_moves] | filter u8[n_moves]; np.repeat of the
+    // board index as numpy_style_repeat_1d_creator does on the device (ann_creation_helper.py:488-510)
+    const size_t from_off = n_moves * sizeof(uint32_t), filter_off = from_off + ((n_moves + 15) & ~(size_t)15);
+    const size_t bytes = filter_off + n_moves;
+    BF_HIP(hipStreamSynchronize(L->stream));   // stage 1 has read the staging buffer
+    if (int r = ensure_staging(L, bytes + 16, n_moves)) return r;
+    uint32_t* idx = reinterpret_cast<uint32_t*>(L->h_in);
+    size_t m = 0;
+    for (size_t b = 0; b < n_boards; ++b)
+        for (unsigned k = 0; k < h_moves_per_board[b]; ++k) idx[m++] = (uint32_t)b;
+    std::memcpy(L->h_in + from_off, h_from, n_moves);
+    std::memcpy(L->h_in + filter_off, h_filter, n_moves);
+    BF_HIP(hipMemcpyAsync(L->d_in, L->h_in, bytes, hipMemcpyHostToDevice, L->stream));
+    BF_HIP(bf::launch_policy_scores(c->d_x9, c->d_policy_packed, reinterpret_cast<const unsigned*>(L->d_in),
+                                    L->d_in + from_off, L->d_in + filter_off, n_moves, n_boards, L->d_err, L->d_scores,
+                                    L->stream));
+    BF_HIP(hipMemcpyAsync(L->h_scores, L->d_scores, n_moves * sizeof(float), hipMemcpyDeviceToHost, L->stream));
+    if (int r = read_err_flag(L, L->stream)) return r;
+    std::memcpy(h_scores, L->h_scores, n_moves * sizeof(float));
     return BF_OK;
 }

@@ -11,7 +11,7 @@ int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 const char* last_error_text();
 
 // canonical blob -> packed image (bf_layout.h); both sized by the caller
-void pack_weights(const float* blob, float* packed);
+void pack_weights(const float* blob, float* packed, bool policy = false);
 
 // canonical blob -> bf16 image (bf_layout_bf16.h), b16::kImageBytes bytes
 void pack_weights_bf16(const float* blob, unsigned char* image);

@@ -32,6 +32,14 @@ constexpr size_t kDebugFloatsPerBoard = 64 * (236 + 128 + 6 * 32) + 16;
 hipError_t launch_eval_f32(const uint8_t* d_mailbox, size_t n, const float* d_packed, float* d_scores,
                            float* d_debug, hipStream_t stream);
 
+// The move-scoring network (packed with pack_weights(..., policy = true)): mailboxes -> x9 features
+// float32 [n][32][64]; then one logit per requested move.
+hipError_t launch_policy_features_f32(const uint8_t* d_mailbox, size_t n, const float* d_packed, float* d_x9,
+                                      hipStream_t stream);
+hipError_t launch_policy_scores(const float* d_x9, const float* d_packed, const unsigned* d_board_index,
+                                const uint8_t* d_from, const uint8_t* d_filter, size_t n_moves, size_t n_boards,
+                                int* d_err, float* d_out, hipStream_t stream);
+
 // Same network, bf16 operands with float32 sums; `d_image` is the image bf::pack_weights_bf16 builds.
 hipError_t launch_eval_bf16(const uint8_t* d_mailbox, size_t n, const unsigned char* d_image, float* d_scores,
                             float* d_debug, hipStream_t stream);

@@ -38,6 +38,9 @@ struct TowerLayer { int k, cin, cout; };
 constexpr TowerLayer kTower[9] = {{1, 236, 512}, {1, 512, 128}, {3, 128, 32}, {3, 32, 32}, {3, 32, 32},
                                   {3, 32, 32},   {3, 32, 32},   {3, 32, 32},  {8, 32, 16}};
 constexpr size_t kWeightFloats = 333608;
+// move-scoring network: no 8x8 layer (and its batch-norm), logit kernel 32 x 73
+constexpr int kPolicyFilters = 73;
+constexpr size_t kPolicyWeightFloats = kWeightFloats - (8 * 8 * 32 * 16 + 3 * 16 + 16) + 32 * kPolicyFilters;
 
 // ---- packed image layout (floats) -----------------------------------------------------
 constexpr int kGroupFloats = 256;  // 64 lanes x 4 k-steps

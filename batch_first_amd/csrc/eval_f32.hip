@@ -237,12 +237,16 @@ __device__ __forceinline__ void conv3x3_chunk(WStream& ws, int g0, const float* 
     }
 }
 
-template <bool DBG>
+// MODE 0: scores; 1: scores + every intermediate activation (debug); 2: features -- x9, the
+// activations after the six 3x3 layers, as float32 [board][32][64] into `scores`, no head (the
+// move-scoring network, whose 1x1 logit layer is applied per requested move by k_policy_scores).
+template <int MODE>
 __global__ __launch_bounds__(THREADS, 2) void k_eval_f32(const uint8_t* __restrict__ mailbox, unsigned n_boards,
                                                           const f32x4* __restrict__ wstream,
                                                           const float* __restrict__ bias,
                                                           const f32x4* __restrict__ headw,
                                                           float* __restrict__ scores, float* __restrict__ dbg) {
+    constexpr bool DBG = MODE == 1;
     __shared__ __attribute__((aligned(16))) Lds lds;
     const int tid = threadIdx.x;
     const int lane = tid & 63, hl = lane >> 5, ln = lane & 31;
@@ -389,6 +393,14 @@ __global__ __launch_bounds__(THREADS, 2) void k_eval_f32(const uint8_t* __restri
     }
 
     BF_STAMP(5);
+    if (MODE == 2) {
+        if (live) {
+            float* out = scores + (size_t)board * 2048;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) out[rowmap(t, hl) * 64 + sq] = relu(acc[t]);
+        }
+        return;
+    }
     // ---- stage 5: 8x8 valid conv (2048 -> 16), ReLU, logit -----------------------------
     float part[16];
 #pragma unroll
@@ -443,7 +455,52 @@ __global__ __launch_bounds__(THREADS, 2) void k_eval_f32(const uint8_t* __restri
 #endif
 }
 
+// One thread per requested move: logit[filter][from] = sum_c W[filter][c] * x9[board][c][from]
+// (logit_layer + reshape + gather_nd, move_evaluation_ann.py:35-73), fixed summation order.
+__global__ __launch_bounds__(256) void k_policy_scores(const float* __restrict__ x9, const float* __restrict__ logit_w,
+                                                       const unsigned* __restrict__ board_index,
+                                                       const uint8_t* __restrict__ from_sq,
+                                                       const uint8_t* __restrict__ move_filter, unsigned n_moves,
+                                                       unsigned n_boards, int* __restrict__ err,
+                                                       float* __restrict__ out) {
+    const unsigned m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= n_moves) return;
+    unsigned b = board_index[m], sq = from_sq[m], f = move_filter[m];
+    if (b >= n_boards || sq >= 64u || f >= (unsigned)kPolicyFilters) {  // reads stay in bounds; the caller is told
+        *err = 4;
+        b = min(b, n_boards - 1);
+        sq &= 63u;
+        f = min(f, (unsigned)kPolicyFilters - 1);
+    }
+    const float* x = x9 + (size_t)b * 2048 + sq;
+    const float* w = logit_w + (size_t)f * 32;
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) s = fmaf(w[c], x[c * 64], s);
+    out[m] = s;
+}
+
 }  // namespace
+
+hipError_t launch_policy_features_f32(const uint8_t* d_mailbox, size_t n, const float* d_packed, float* d_x9,
+                                      hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const f32x4* ws = reinterpret_cast<const f32x4*>(d_packed + kOffStream);
+    const unsigned blocks = (unsigned)((n + BPB - 1) / BPB);
+    hipLaunchKernelGGL(k_eval_f32<2>, dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, (unsigned)n, ws,
+                       d_packed + kOffBias, reinterpret_cast<const f32x4*>(d_packed + kOffHead), d_x9, nullptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_policy_scores(const float* d_x9, const float* d_packed, const unsigned* d_board_index,
+                                const uint8_t* d_from, const uint8_t* d_filter, size_t n_moves, size_t n_boards,
+                                int* d_err, float* d_out, hipStream_t stream) {
+    if (n_moves == 0 || n_boards == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_policy_scores, dim3((unsigned)((n_moves + 255) / 256)), dim3(256), 0, stream, d_x9,
+                       d_packed + kOffHead, d_board_index, d_from, d_filter, (unsigned)n_moves, (unsigned)n_boards,
+                       d_err, d_out);
+    return hipGetLastError();
+}
 
 hipError_t launch_eval_f32(const uint8_t* d_mailbox, size_t n, const float* d_packed, float* d_scores,
                            float* d_debug, hipStream_t stream) {
@@ -457,10 +514,10 @@ hipError_t launch_eval_f32(const uint8_t* d_mailbox, size_t n, const float* d_pa
 #else
     if (d_debug)
 #endif
-        hipLaunchKernelGGL(k_eval_f32<true>, dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, (unsigned)n, ws,
+        hipLaunchKernelGGL(k_eval_f32<1>, dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, (unsigned)n, ws,
                            bias, head, d_scores, d_debug);
     else
-        hipLaunchKernelGGL(k_eval_f32<false>, dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, (unsigned)n, ws,
+        hipLaunchKernelGGL(k_eval_f32<0>, dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, (unsigned)n, ws,
                            bias, head, d_scores, d_debug);
     return hipGetLastError();
 }

@@ -24,7 +24,9 @@ struct Canonical {
     const float* logit_w;
 };
 
-Canonical slice(const float* blob) {
+// `policy`: the move-scoring network's blob (batch_first/anns/move_evaluation_ann.py:18-45, :280, :291):
+// same input convs and tower without the 8x8 layer, logit kernel [1][1][32][73].
+Canonical slice(const float* blob, bool policy = false) {
     Canonical c;
     size_t pos = 0;
     for (int i = 0; i < kNumInputConvs; ++i) {
@@ -38,13 +40,19 @@ Canonical slice(const float* blob) {
         pos += 3 * (size_t)ch;
     };
     bn(0, kX1Channels);
+    const int layers = policy ? 8 : 9;
     for (int j = 0; j < 9; ++j) {
+        if (j >= layers) {
+            c.tower_w[j] = nullptr;
+            c.bn_mean[j + 1] = c.bn_var[j + 1] = c.bn_beta[j + 1] = nullptr;
+            continue;
+        }
         c.tower_w[j] = blob + pos;
         pos += (size_t)kTower[j].k * kTower[j].k * kTower[j].cin * kTower[j].cout;
         bn(j + 1, kTower[j].cout);
     }
     c.logit_w = blob + pos;
-    pos += 16;
+    pos += policy ? kPolicyFilters * 32 : 16;
     return c;
 }
 
@@ -80,8 +88,8 @@ void split_bf16x3(float w, uint16_t out[3]) {
 
 }  // namespace
 
-void pack_weights(const float* blob, float* packed) {
-    const Canonical c = slice(blob);
+void pack_weights(const float* blob, float* packed, bool policy) {
+    const Canonical c = slice(blob, policy);
     std::memset(packed, 0, kPackedFloats * sizeof(float));
 
     // folded scale per batch-norm layer
@@ -90,7 +98,7 @@ void pack_weights(const float* blob, float* packed) {
     float* bias = packed + kOffBias;
     const int bias_off[10] = {kBiasX1, kBiasX2, kBiasX3, kBiasX4, kBiasX4 + 32, kBiasX4 + 64,
                               kBiasX4 + 96, kBiasX4 + 128, kBiasX4 + 160, kBiasX10};
-    for (int l = 0; l < 10; ++l) {
+    for (int l = 0; l < (policy ? 9 : 10); ++l) {
         inv[l].resize(bn_ch[l]);
         for (int ch = 0; ch < bn_ch[l]; ++ch) {
             float s = 1.0f / std::sqrt(c.bn_var[l][ch] + kBnEps);
@@ -98,7 +106,8 @@ void pack_weights(const float* blob, float* packed) {
             bias[bias_off[l] + ch] = c.bn_beta[l][ch] - c.bn_mean[l][ch] * s;
         }
     }
-    for (int co = 0; co < 16; ++co) bias[kLogitW + co] = c.logit_w[co];
+    if (!policy)
+        for (int co = 0; co < 16; ++co) bias[kLogitW + co] = c.logit_w[co];
 
     // ---- A-fragment stream -----------------------------------------------------------
     float* stream = packed + kOffStream;
@@ -173,6 +182,13 @@ void pack_weights(const float* blob, float* packed) {
 
     // ---- head: 8x8 valid conv as a 2048 -> 16 dense layer --------------------------
     float* head = packed + kOffHead;
+    if (policy) {
+        // no 8x8 layer: the head region carries the logit kernel transposed to [filter][channel]
+        // (logit_layer: 1x1, 32 -> 73, no bias, move_evaluation_ann.py:35-44)
+        for (int f = 0; f < kPolicyFilters; ++f)
+            for (int ci = 0; ci < 32; ++ci) head[f * 32 + ci] = c.logit_w[ci * kPolicyFilters + f];
+        return;
+    }
     for (int half = 0; half < 2; ++half)
         for (int t = 0; t < 16; ++t)
             for (int cq = 0; cq < 4; ++cq)
@@ -189,12 +205,22 @@ void pack_weights(const float* blob, float* packed) {
 
 extern "C" size_t bf_packed_floats(void) { return bf::kPackedFloats; }
 
+extern "C" int bf_pack_policy_weights(const float* h_weights, size_t n_floats, float* h_packed, size_t n_packed) {
+    if (!h_weights || !h_packed) return bf::fail(BF_E_ARG, "bf_pack_policy_weights: null pointer");
+    if (n_floats != bf::kPolicyWeightFloats)
+        return bf::fail(BF_E_ARG, "bf_pack_policy_weights: expected %zu weight floats, got %zu", bf::kPolicyWeightFloats, n_floats);
+    if (n_packed != bf::kPackedFloats)
+        return bf::fail(BF_E_ARG, "bf_pack_policy_weights: expected room for %zu packed floats, got %zu", bf::kPackedFloats, n_packed);
+    bf::pack_weights(h_weights, h_packed, true);
+    return BF_OK;
+}
+
 extern "C" int bf_pack_weights(const float* h_weights, size_t n_floats, float* h_packed, size_t n_packed) {
     if (!h_weights || !h_packed) return bf::fail(BF_E_ARG, "bf_pack_weights: null pointer");
     if (n_floats != bf::kWeightFloats)
         return bf::fail(BF_E_ARG, "bf_pack_weights: expected %zu weight floats, got %zu", bf::kWeightFloats, n_floats);
     if (n_packed != bf::kPackedFloats)
         return bf::fail(BF_E_ARG, "bf_pack_weights: expected room for %zu packed floats, got %zu", bf::kPackedFloats, n_packed);
-    bf::pack_weights(h_weights, h_packed);
+    bf::pack_weights(h_weights, h_packed, false);
     return BF_OK;
 }

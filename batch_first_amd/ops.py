@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .chestimator import _as_blob
+from .chestimator import _as_blob, _as_policy_blob
 
 _contexts = {}
 
@@ -37,6 +37,13 @@ class DeviceContext:
         self.device = torch.device("cuda", int(device))
         self.handle = int(ctx.value)
         _contexts[self.handle] = self
+
+    def set_policy(self, policy_weights):
+        blob = _as_policy_blob(policy_weights)
+        _lib.check(self._lib.bf_ctx_set_policy(self._ctx, blob.ctypes.data, blob.size))
+
+    def check_policy(self):
+        _lib.check(self._lib.bf_policy_check(self._ctx, _stream(self.device)))
 
     def check(self):
         """Synchronise the current stream and raise ValueError if a wire input was malformed."""
@@ -145,6 +152,51 @@ def encode_mailbox_structs(ctx: int, records: torch.Tensor) -> torch.Tensor:
     out = torch.empty((recs.shape[0], 32), dtype=torch.uint8, device=recs.device)
     _lib.check(c._lib.bf_encode_mailbox_structs(c._ctx, recs.data_ptr(), recs.shape[1], recs.shape[0],
                                                 out.data_ptr(), _stream(recs.device)))
+    return out
+
+
+@torch.library.custom_op("batchfirst::policy_features_wire", mutates_args=())
+def policy_features_wire(ctx: int, piece_filters: torch.Tensor, occupied_bbs: torch.Tensor) -> torch.Tensor:
+    c = _ctx(ctx)
+    pf = _dev(piece_filters, torch.uint8, "piece_filters")
+    occ = _dev(occupied_bbs, torch.int64, "occupied_bbs")
+    out = torch.empty((occ.numel(), 32, 8, 8), dtype=torch.float32, device=occ.device)
+    _lib.check(c._lib.bf_policy_features_wire(c._ctx, pf.data_ptr(), pf.numel(), occ.data_ptr(), occ.numel(),
+                                              out.data_ptr(), _stream(occ.device)))
+    return out
+
+
+@torch.library.custom_op("batchfirst::policy_features_structs", mutates_args=())
+def policy_features_structs(ctx: int, records: torch.Tensor) -> torch.Tensor:
+    c = _ctx(ctx)
+    recs = _dev(records, torch.uint8, "records")
+    if recs.dim() != 2:
+        raise ValueError("records must be uint8[N, stride]")
+    out = torch.empty((recs.shape[0], 32, 8, 8), dtype=torch.float32, device=recs.device)
+    _lib.check(c._lib.bf_policy_features_structs(c._ctx, recs.data_ptr(), recs.shape[1], recs.shape[0],
+                                                 out.data_ptr(), _stream(recs.device)))
+    return out
+
+
+@torch.library.custom_op("batchfirst::policy_scores", mutates_args=())
+def policy_scores(ctx: int, features: torch.Tensor, from_squares: torch.Tensor, move_filters: torch.Tensor,
+                  moves_per_board: torch.Tensor) -> torch.Tensor:
+    """Stage 2: one score per move; the three move tensors are uint8 device tensors."""
+    c = _ctx(ctx)
+    x9 = _dev(features, torch.float32, "features")
+    frm = _dev(from_squares, torch.uint8, "from_squares")
+    flt = _dev(move_filters, torch.uint8, "move_filters")
+    per = _dev(moves_per_board, torch.uint8, "moves_per_board")
+    n = x9.shape[0]
+    if per.numel() != n or frm.numel() != flt.numel():
+        raise ValueError("moves_per_board needs one entry per board, from_squares and move_filters one per move")
+    # np.repeat of the board index, as numpy_style_repeat_1d_creator does (ann_creation_helper.py:488-510)
+    board_index = torch.repeat_interleave(torch.arange(n, device=x9.device, dtype=torch.int32), per.to(torch.int64))
+    if board_index.numel() != frm.numel():
+        raise ValueError("moves_per_board sums to %d, but %d moves were given" % (board_index.numel(), frm.numel()))
+    out = torch.empty(frm.numel(), dtype=torch.float32, device=x9.device)
+    _lib.check(c._lib.bf_policy_scores(c._ctx, x9.data_ptr(), n, board_index.data_ptr(), frm.data_ptr(), flt.data_ptr(),
+                                       frm.numel(), out.data_ptr(), _stream(x9.device)))
     return out
 
 

@@ -104,3 +104,26 @@ def macs_per_board(in_bounds=True):
 
 
 FLOPS_PER_BOARD = 2 * macs_per_board(True)  # 34 976 560, the figure SURVEY.md 8(d) fixes
+
+
+# ---- the move-scoring ("policy") network --------------------------------------------------
+# batch_first/anns/move_evaluation_ann.py: same input convolutions (:18-23), tower without the
+# 8x8 layer (CONVOLUTIONAL_MODULES, :291), 73 logit filters (:280).
+POLICY_TOWER = TOWER[:8]
+POLICY_LOGIT_IN = 32
+POLICY_FILTERS = 73
+
+
+def policy_layer_shapes():
+    """HWIO kernel shapes: 9 input convs, 8 tower convs, logit."""
+    shapes = [(k, k, NUM_PLANES, c) for k, _, c in INPUT_CONVS]
+    cin = INPUT_CHANNELS
+    for cout, k, _ in POLICY_TOWER:
+        shapes.append((k, k, cin, cout))
+        cin = cout
+    shapes.append((1, 1, POLICY_LOGIT_IN, POLICY_FILTERS))
+    return shapes
+
+
+def policy_bn_channels():
+    return [INPUT_CHANNELS] + [c for c, _, _ in POLICY_TOWER]

@@ -108,3 +108,43 @@ def from_blob(blob):
 
 def blob_sha256(blob):
     return hashlib.sha256(np.ascontiguousarray(blob, np.float32).tobytes()).hexdigest()
+
+
+# ---- the move-scoring ("policy") network: same recipe, its own shapes ------------------------
+
+def make_policy_weights(seed=4321, bn="perturbed"):
+    """``{"convs": [HWIO x18], "bn": [(mean, var, beta) x9]}`` for the policy network
+    (batch_first/anns/move_evaluation_ann.py:18-45, :280, :291)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    convs = []
+    for shape in spec.policy_layer_shapes():
+        kh, kw, cin, _ = shape
+        convs.append(_truncated_normal(rng, shape, np.sqrt(1.3 * 2.0 / (kh * kw * cin))))
+    bns = []
+    for c in spec.policy_bn_channels():
+        if bn == "fresh":
+            bns.append((np.zeros(c, np.float32), np.ones(c, np.float32), np.zeros(c, np.float32)))
+        elif bn == "perturbed":
+            bns.append(((rng.standard_normal(c) * 0.1).astype(np.float32), rng.uniform(0.5, 1.5, c).astype(np.float32),
+                        (rng.standard_normal(c) * 0.1).astype(np.float32)))
+        else:
+            raise ValueError("bn must be 'fresh' or 'perturbed'")
+    return {"convs": convs, "bn": bns}
+
+
+def policy_blob_size():
+    return sum(int(np.prod(s)) for s in spec.policy_layer_shapes()) + 3 * sum(spec.policy_bn_channels())
+
+
+def to_policy_blob(weights):
+    """Canonical float32 blob of the policy network (include/batchfirst.h, BF_POLICY_WEIGHT_FLOATS)."""
+    convs, bns = weights["convs"], weights["bn"]
+    parts = [np.ascontiguousarray(w, np.float32).ravel() for w in convs[:9]]
+    parts += [np.ascontiguousarray(a, np.float32) for a in bns[0]]
+    for j in range(8):
+        parts.append(np.ascontiguousarray(convs[9 + j], np.float32).ravel())
+        parts += [np.ascontiguousarray(a, np.float32) for a in bns[1 + j]]
+    parts.append(np.ascontiguousarray(convs[17], np.float32).ravel())
+    blob = np.concatenate(parts)
+    assert blob.size == policy_blob_size()
+    return blob

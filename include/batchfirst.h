@@ -157,6 +157,57 @@ int bf_eval_wire_host(bf_ctx* ctx, const uint8_t* h_piece_filters, size_t n_byte
 int bf_eval_structs_host(bf_ctx* ctx, const void* h_structs, size_t stride, const uint8_t* h_mask,
                          size_t n, float* h_scores, size_t* n_scored);
 
+/* ---- the move-scoring ("policy") network ------------------------------------------------
+ *
+ * batch_first/anns/move_evaluation_ann.py:10-73: the same nine input convolutions and tower as
+ * the value network minus its 8x8 layer ([[512,1],[128,1]] + 6*[[32,3]], :291), a bias-free 1x1
+ * logit conv 32 -> 73 (:35-44, NUM_LOGIT_FILTERS :280), reshaped to [boards][73][64] and gathered
+ * at (board, move_filter, from_square) (:46-73).  The reference runs it in two stages through
+ * session.partial_run (batch_first/chestimator.py:40-46): stage 1 is fed the boards, the search
+ * generates moves meanwhile, stage 2 is fed (from_square, move_filter, moves_per_board) and
+ * returns one score per move.  Here stage 1 leaves the 32 x 64 activations in front of the logit
+ * layer on the GPU and stage 2 applies the logit kernel only where a move asks for it.
+ *
+ * Weights: float32 blob of BF_POLICY_WEIGHT_FLOATS, laid out as the value network's with the
+ * 8x8 layer and its batch-norm left out and the logit kernel HWIO [1][1][32][73].  float32 only.
+ * Squares and filters arrive in the mover's frame (SQUARES_180 for black,
+ * numba_negamax_zero_window.py:512-515; MOVE_FILTER_LOOKUP, batch_first/__init__.py:51-95). */
+#define BF_POLICY_WEIGHT_FLOATS 303112u
+#define BF_POLICY_FILTERS 73u
+#define BF_POLICY_FEATURES_PER_BOARD 2048u /* 32 channels x 64 squares */
+
+/* Attach (or replace) the move-scoring network of a context.  Stands in for the policy_network/
+ * half of the frozen graph: chestimator.py:23-26, ann_creation_helper.py:130-146. */
+int bf_ctx_set_policy(bf_ctx* ctx, const float* h_weights, size_t n_floats);
+
+/* Stage 1 on device pointers: features float32 [n][32][64] of the boards (asynchronous). */
+int bf_policy_features_wire(bf_ctx* ctx, const uint8_t* d_piece_filters, size_t n_bytes,
+                            const uint64_t* d_occupied_bbs, size_t n, float* d_features, void* stream);
+int bf_policy_features_structs(bf_ctx* ctx, const void* d_structs, size_t stride, size_t n,
+                               float* d_features, void* stream);
+
+/* Stage 2 on device pointers: scores[m] = logits[board_index[m]][move_filter[m]][from_square[m]]
+ * ("policy_network/requested_move_scores", move_evaluation_ann.py:73).  board_index is the
+ * np.repeat of arange(n_boards) by moves_per_board (move_evaluation_ann.py:59-61).  Out-of-range
+ * values are clamped and reported by bf_policy_check(). */
+int bf_policy_scores(bf_ctx* ctx, const float* d_features, size_t n_boards, const uint32_t* d_board_index,
+                     const uint8_t* d_from_square, const uint8_t* d_move_filter, size_t n_moves,
+                     float* d_scores, void* stream);
+int bf_policy_check(bf_ctx* ctx, void* stream);
+
+/* start_move_prediction(piece_filters, occupied_bbs) (chestimator.py:40-42): copies the boards in
+ * and starts stage 1 on the context's policy stream, then returns; at most one prediction per
+ * context is in flight (a new start abandons an unfinished one).  May overlap a value-network
+ * call from another thread (numba_negamax_zero_window.py:178,199). */
+int bf_policy_start_wire_host(bf_ctx* ctx, const uint8_t* h_piece_filters, size_t n_bytes,
+                              const uint64_t* h_occupied_bbs, size_t n);
+
+/* The closure start_move_prediction returns (chestimator.py:44-46): feed move_info =
+ * (from_square, move_filter, moves_per_board), all uint8 (move_evaluation_ann.py:244-246), get one
+ * float32 score per move, boards' moves back to back.  n_boards must equal the started n. */
+int bf_policy_finish_host(bf_ctx* ctx, const uint8_t* h_from_square, const uint8_t* h_move_filter,
+                          const uint8_t* h_moves_per_board, size_t n_boards, size_t n_moves, float* h_scores);
+
 /* ---- host-only helpers (no GPU needed) ----------------------------------------------- */
 
 /* The host encoder itself, for callers that still want the wire format:
@@ -171,6 +222,8 @@ int bf_host_encode_wire(const void* h_structs, size_t stride, const uint8_t* h_m
  * (bf_ctx_create uploads exactly this).  Exposed so the arrangement can be checked on a CPU. */
 size_t bf_packed_floats(void);
 int bf_pack_weights(const float* h_weights, size_t n_floats, float* h_packed, size_t n_packed);
+
+int bf_pack_policy_weights(const float* h_weights, size_t n_floats, float* h_packed, size_t n_packed);
 
 /* The same for the bf16 image (bytes). */
 size_t bf_packed_bf16_bytes(void);

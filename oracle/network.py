@@ -237,3 +237,50 @@ def bf16_model_layer(x_in, weights, layer, double=False):
         else:
             x = step(x, 7 + int(layer[1:]), "same", True)
     return x.to(torch.float32).numpy()
+
+
+# ---- the move-scoring ("policy") network ---------------------------------------------------
+# batch_first/anns/move_evaluation_ann.py:10-73: input convs (:18-23), tower
+# CONVOLUTIONAL_MODULES = [[[[512,1],[128,1]] + 6*[[32,3]]]] (:291), bias-free 1x1 logit conv to 73
+# filters (:35-44, :280), reshape to [N, 73, 64] (NCHW, :54-57) and gather_nd at
+# (board, move_filter, move_from_square) (:68-73) with board = np.repeat(arange, moves_per_board)
+# (:59-61).  PARITY UNPINNED for scores, as for the value network.
+POLICY_MODULES = [[[[512, 1], [128, 1]] + 6 * [[32, 3]]]]
+
+
+def policy_logits_torch(planes, weights, double=False):
+    """All 73 x 64 logits per board, [N, 73, 64] ("policy_network/Reshape", chestimator.py:59)."""
+    import torch
+    import torch.nn.functional as F
+
+    convs, bns = weights["convs"], weights["bn"]
+    dt = torch.float64 if double else torch.float32
+
+    def t(a):
+        return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dt)
+
+    def conv(x, w_hwio, dil=(1, 1)):
+        w = t(np.transpose(w_hwio, (3, 2, 0, 1)))
+        k = w_hwio.shape[0]
+        pt, pb = _same_pads(k, dil[0])
+        pl, pr = _same_pads(k, dil[1])
+        return F.conv2d(F.pad(x, (pl, pr, pt, pb)), w, dilation=dil)
+
+    def bn_relu(x, bn):
+        mean, var, beta = (t(a).view(1, -1, 1, 1) for a in bn)
+        return torch.relu((x - mean) / torch.sqrt(var + BN_EPS) + beta)
+
+    with torch.no_grad():
+        x0 = t(planes)
+        x = bn_relu(torch.cat([conv(x0, convs[i], dil) for i, (_, dil) in enumerate(INPUT_CONV_GEOMETRY)], dim=1), bns[0])
+        for j in range(8):
+            x = bn_relu(conv(x, convs[9 + j]), bns[1 + j])
+        logits = conv(x, convs[17])
+    n = logits.shape[0]
+    return logits.reshape(n, 73, 64).numpy(), x.numpy()
+
+
+def policy_gather(logits, from_squares, move_filters, moves_per_board):
+    """requested_move_scores: one score per move (move_evaluation_ann.py:59-73)."""
+    board = np.repeat(np.arange(len(moves_per_board)), np.asarray(moves_per_board, np.int64))
+    return logits[board, np.asarray(move_filters, np.int64), np.asarray(from_squares, np.int64)]
