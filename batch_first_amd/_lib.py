@@ -53,6 +53,7 @@ SIGNATURES = {
     "bf_policy_scores": (_int, [_vp, _vp, _sz, _vp, _vp, _vp, _sz, _vp, _vp]),
     "bf_policy_check": (_int, [_vp, _vp]),
     "bf_policy_start_wire_host": (_int, [_vp, _vp, _sz, _vp, _sz]),
+    "bf_policy_start_structs_host": (_int, [_vp, _vp, _sz, _vp, _sz]),
     "bf_policy_finish_host": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _vp]),
     "bf_packed_bf16_bytes": (_sz, []),
     "bf_pack_weights_bf16": (_int, [_vp, _sz, _vp, _sz]),

@@ -507,6 +507,42 @@ extern "C" int bf_policy_start_wire_host(bf_ctx* c, const uint8_t* h_pf, size_t 
     return BF_OK;   // the GPU works on while the caller generates the moves to score
 }
 
+extern "C" int bf_policy_start_structs_host(bf_ctx* c, const void* h_structs, size_t stride, const uint8_t* h_mask, size_t n) {
+    if (int r = check_policy(c, n, "bf_policy_start_structs_host")) return r;
+    if (n && !h_structs) return bf::fail(BF_E_ARG, "bf_policy_start_structs_host: null pointer");
+    if (stride < BF_NODE_EVAL_BYTES) return bf::fail(BF_E_ARG, "bf_policy_start_structs_host: stride %zu < 82", stride);
+    DeviceGuard guard(c->device);
+    Lane* L = &c->policy;
+    std::lock_guard<std::mutex> lock(L->mu);
+    c->policy_started = false;
+    constexpr size_t kCompact = 88;
+    size_t m = 0;
+    if (h_mask) {
+        for (size_t j = 0; j < n; ++j) m += h_mask[j] ? 1 : 0;
+    } else {
+        m = n;
+    }
+    if (m) {
+        BF_HIP(hipStreamSynchronize(L->stream));
+        if (int r = ensure_boards(L, m)) return r;
+        if (int r = ensure_x9(c, m)) return r;
+        if (int r = ensure_staging(L, m * kCompact, 1)) return r;
+        const unsigned char* recs = static_cast<const unsigned char*>(h_structs);
+        size_t k = 0;
+        for (size_t j = 0; j < n; ++j) {
+            if (h_mask && !h_mask[j]) continue;
+            std::memcpy(L->h_in + k * kCompact, recs + j * stride, BF_NODE_EVAL_BYTES);
+            ++k;
+        }
+        BF_HIP(hipMemcpyAsync(L->d_in, L->h_in, m * kCompact, hipMemcpyHostToDevice, L->stream));
+        BF_HIP(bf::launch_mailbox_from_structs(L->d_in, kCompact, m, L->d_mailbox, L->stream));
+        BF_HIP(bf::launch_policy_features_f32(L->d_mailbox, m, c->d_policy_packed, c->d_x9, L->stream));
+    }
+    c->policy_boards = m;
+    c->policy_started = true;
+    return BF_OK;
+}
+
 extern "C" int bf_policy_finish_host(bf_ctx* c, const uint8_t* h_from, const uint8_t* h_filter,
                                      const uint8_t* h_moves_per_board, size_t n_boards, size_t n_moves, float* h_scores) {
     if (int r = check_policy(c, n_boards, "bf_policy_finish_host")) return r;

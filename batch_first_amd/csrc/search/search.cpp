@@ -1,0 +1,783 @@
+// See search.h.
+#include "search.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "board.h"
+
+using namespace bfs;
+
+namespace {
+
+constexpr float FMAX = FLT_MAX, FMIN = -FLT_MAX;
+constexpr float TIE = 0.0f;                      // TIE_RESULT_SCORE
+constexpr int kMaxDepth = 100;                   // MAX_SEARCH_DEPTH
+constexpr uint8_t kNoMoreMoves = 255;            // NO_MORE_MOVES_VALUE
+constexpr uint8_t kNoEntry = 255;                // NO_TT_ENTRY_VALUE
+
+float g_win[kMaxDepth], g_loss[kMaxDepth], g_tt_move_score;
+uint8_t g_filter[64][64][6];
+std::once_flag g_const_once;
+
+// batch_first/__init__.py:119-165 (score sentinels) and :51-95 (move filter table)
+void build_constants() {
+    init_tables();
+    const float almost_max = std::nextafterf(FMAX, FMIN), almost_min = std::nextafterf(FMIN, FMAX);
+    g_tt_move_score = almost_max;
+    g_win[0] = std::nextafterf(almost_max, FMIN);
+    g_loss[0] = std::nextafterf(almost_min, FMAX);
+    for (int j = 1; j < kMaxDepth; ++j) {
+        g_win[j] = std::nextafterf(g_win[j - 1], FMIN);
+        g_loss[j] = std::nextafterf(g_loss[j - 1], FMAX);
+    }
+    std::memset(g_filter, 0, sizeof g_filter);
+    for (int a = 0; a < 64; ++a)
+        for (int b = 0; b < 64; ++b) {
+            const int fd = (b & 7) - (a & 7), rd = (b >> 3) - (a >> 3);
+            int plane = -1;
+            if (fd == 0 && rd > 0) plane = rd - 1;
+            else if (fd == 0 && rd < 0) plane = -rd + 6;
+            else if (rd == 0 && fd > 0) plane = fd + 13;
+            else if (rd == 0 && fd < 0) plane = -fd + 20;
+            else if (fd == rd && fd > 0) plane = fd + 27;
+            else if (fd == -rd && fd > 0) plane = fd + 34;
+            else if (fd == -rd && fd < 0) plane = -fd + 41;
+            else if (fd == rd && fd < 0) plane = -fd + 48;
+            else if (fd == 1 && rd == 2) plane = 56;
+            else if (fd == 1 && rd == -2) plane = 57;
+            else if (fd == -1 && rd == 2) plane = 58;
+            else if (fd == -1 && rd == -2) plane = 59;
+            else if (fd == 2 && rd == 1) plane = 60;
+            else if (fd == 2 && rd == -1) plane = 61;
+            else if (fd == -2 && rd == 1) plane = 62;
+            else if (fd == -2 && rd == -1) plane = 63;
+            if (plane < 0) continue;
+            for (int p = 0; p < 6; ++p) g_filter[a][b][p] = (uint8_t)plane;
+            if (rd == 1 && fd >= -1 && fd <= 1)
+                for (int p = 2; p < 5; ++p) g_filter[a][b][p] = (uint8_t)(3 * (1 + fd) + 64 + (p - 2));
+        }
+}
+
+thread_local char g_err[512] = "";
+int fail(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return -1;
+}
+
+struct TTEntry {
+    u64 hash = 0;
+    float upper = FMAX, lower = FMIN;
+    uint8_t depth = kNoEntry;
+    Move move = kNoMove;
+};
+
+struct Node {
+    Board b;
+    int parent;
+    float separator, best_value;
+    uint8_t depth;
+    bool terminated;
+    uint8_t n_moves, next_move_index, children_left;
+    Move prev_move;
+    Move moves[kMaxMoves];
+    float move_scores[kMaxMoves];
+};
+
+double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+}  // namespace
+
+struct bfs_search {
+    bfs_config cfg;
+    std::vector<float> bins_desc;
+    std::vector<TTEntry> tt;
+    u64 tt_mask = 0;
+    std::vector<Node> nodes;
+    std::vector<std::vector<int>> bins;
+    size_t in_bins = 0;
+    bfs_stats stats{};
+    std::string error;
+
+    // ---- transposition table (transposition_table.py) ------------------------------------
+    TTEntry& entry(u64 h) { return tt[h & tt_mask]; }
+
+    void tt_add(const Node& n, Move following) {  // add_board_and_move_to_tt, :86-133
+        TTEntry& e = entry(n.b.hash);
+        const bool lower_side = n.best_value >= n.separator;
+        if (e.depth != kNoEntry) {
+            if (e.hash == n.b.hash) {
+                if (e.depth == n.depth) {
+                    if (lower_side) {
+                        if (n.best_value > e.lower) {
+                            e.lower = n.best_value;
+                            e.move = following;
+                        }
+                    } else if (n.best_value < e.upper) {
+                        e.upper = n.best_value;
+                    }
+                } else if (e.depth < n.depth) {
+                    e.depth = n.depth;
+                    if (lower_side) {
+                        e.move = following;
+                        e.upper = FMAX;
+                        e.lower = n.best_value;
+                    } else {
+                        e.upper = n.best_value;
+                        e.lower = FMIN;
+                    }
+                }
+            } else {  // always replace
+                e.hash = n.b.hash;
+                e.depth = n.depth;
+                if (lower_side) {
+                    e.move = following;
+                    e.upper = FMAX;
+                    e.lower = n.best_value;
+                } else {
+                    e.move = kNoMove;
+                    e.upper = n.best_value;
+                    e.lower = FMIN;
+                }
+            }
+        } else {
+            e.hash = n.b.hash;
+            e.depth = n.depth;
+            if (lower_side) {
+                e.move = following;
+                e.lower = n.best_value;
+            } else {
+                e.upper = n.best_value;
+            }
+        }
+    }
+
+    // should_terminate_from_tt, numba_negamax_zero_window.py:203-222
+    bool tt_terminates(Node& n) {
+        const TTEntry& e = entry(n.b.hash);
+        if (e.depth != kNoEntry && e.hash == n.b.hash && e.depth >= n.depth) {
+            if (e.lower >= n.separator) {
+                n.best_value = e.lower;
+                return true;
+            }
+            if (e.upper < n.separator) {
+                n.best_value = e.upper;
+                return true;
+            }
+            if (e.lower > n.best_value) n.best_value = e.lower;
+        }
+        return false;
+    }
+
+    // ---- tree updates (numba_negamax_zero_window.py:399-419) --------------------------------
+    void update_from_value(int id, float value, Move following, bool new_termination = true) {
+        while (id >= 0) {
+            Node& n = nodes[id];
+            if (n.terminated) {
+                if (!(value > n.best_value)) return;
+                n.best_value = value;
+                tt_add(n, following);
+                value = -value;
+                following = n.prev_move;
+                id = n.parent;
+                new_termination = false;
+            } else {
+                if (new_termination) n.children_left -= 1;
+                n.best_value = std::max(value, n.best_value);
+                if (!(n.best_value >= n.separator || n.children_left == 0)) return;
+                n.terminated = true;
+                tt_add(n, following);
+                value = -n.best_value;
+                following = n.prev_move;
+                id = n.parent;
+                new_termination = true;
+            }
+        }
+    }
+
+    bool should_not_terminate(int id) const {  // global_open_priority_nodes.py:4-11
+        for (; id >= 0; id = nodes[id].parent)
+            if (nodes[id].terminated) return false;
+        return true;
+    }
+
+    // can_draw_from_repetition, numba_negamax_zero_window.py:109-149 (no pre-search game history)
+    bool repetition(const Node& child) const {
+        if (child.b.halfmove < 4) return false;
+        int found = 1;
+        if (child.parent < 0 || nodes[child.parent].parent < 0) return false;
+        int id = nodes[child.parent].parent;
+        if (nodes[id].b.hash == child.b.hash) ++found;
+        if (found >= 3) return true;
+        for (int num = nodes[id].b.halfmove; num > 1; num -= 2) {
+            if (num < 3 && found == 1) return false;
+            if (nodes[id].parent < 0 || nodes[nodes[id].parent].parent < 0) return false;
+            id = nodes[nodes[id].parent].parent;
+            if (nodes[id].b.hash == child.b.hash && ++found >= 3) return true;
+        }
+        return false;
+    }
+
+    static float next_best_move(Node& n) {  // set_up_next_best_move, :152-161
+        int best = 0;
+        for (int i = 1; i < n.n_moves; ++i)
+            if (n.move_scores[i] > n.move_scores[best]) best = i;
+        const float s = n.n_moves ? n.move_scores[best] : FMIN;
+        if (s == FMIN) n.next_move_index = kNoMoreMoves;
+        else {
+            n.next_move_index = (uint8_t)best;
+            n.move_scores[best] = FMIN;
+        }
+        return s;
+    }
+
+    // Draw / table / mate checks and move generation for a freshly made node
+    // (depth_zero_should_terminate_array :227-259, child_termination_check_and_move_gen :284-312).
+    // Returns true when the node still needs work: an evaluation (depth 0) or move scores (depth > 0).
+    bool settle(Node& n) {
+        if (n.b.halfmove >= 50 || insufficient_material(n.b)) {
+            n.terminated = true;
+            n.best_value = TIE;
+            return false;
+        }
+        if (repetition(n)) {
+            n.terminated = true;
+            n.best_value = TIE;
+            return false;
+        }
+        if (tt_terminates(n)) {
+            n.terminated = true;
+            return false;
+        }
+        if (n.depth == 0) {
+            if (has_legal_move(n.b)) return true;
+            n.terminated = true;
+            n.best_value = in_check(n.b) ? g_loss[0] : TIE;
+            return false;
+        }
+        n.n_moves = (uint8_t)legal_moves(n.b, n.moves);
+        n.children_left = n.n_moves;
+        if (!n.n_moves) {
+            n.terminated = true;
+            n.best_value = in_check(n.b) ? g_loss[n.depth] : TIE;
+            return false;
+        }
+        return true;
+    }
+
+    // A legal move stored in the table goes first (has_legal_tt_move, :262-281).
+    void apply_tt_move(Node& n) {
+        const TTEntry& e = entry(n.b.hash);
+        if (e.depth == kNoEntry || e.hash != n.b.hash || e.move.from == 255) return;
+        for (int i = 0; i < n.n_moves; ++i)
+            if (n.moves[i] == e.move) {
+                n.move_scores[i] = g_tt_move_score;
+                return;
+            }
+    }
+
+    // Scores the moves of the listed nodes with the move-scoring network (start_move_scoring
+    // :164-180, get_move_from_and_filter_squares_and_sizes :485-527) or with the reference's fake.
+    int score_moves(const std::vector<Node*>& who, double* wait) {
+        if (who.empty()) return 0;
+        size_t total = 0;
+        for (Node* n : who) total += n->n_moves;
+        std::vector<float> scores(total);
+        if (cfg.move_start && cfg.move_finish) {
+            std::vector<EvalRecord> recs(who.size());
+            std::vector<uint8_t> from(total), filt(total), per(who.size());
+            size_t m = 0;
+            for (size_t i = 0; i < who.size(); ++i) {
+                const Node& n = *who[i];
+                to_record(n.b, &recs[i]);
+                per[i] = n.n_moves;
+                const int flip = n.b.turn ? 0 : 56;  // SQUARES_180 for black: the mover's frame
+                for (int k = 0; k < n.n_moves; ++k, ++m) {
+                    const int f = n.moves[k].from ^ flip, t = n.moves[k].to ^ flip;
+                    from[m] = (uint8_t)f;
+                    filt[m] = g_filter[f][t][n.moves[k].promo < 6 ? n.moves[k].promo : 0];
+                }
+            }
+            const double t0 = now();
+            if (cfg.move_start(cfg.move_user, recs.data(), sizeof(EvalRecord), nullptr, recs.size()))
+                return fail("the move-scoring network's start call failed");
+            if (cfg.move_finish(cfg.move_user, from.data(), filt.data(), per.data(), per.size(), total, scores.data()))
+                return fail("the move-scoring network's finish call failed");
+            *wait += now() - t0;
+        } else {
+            for (size_t i = 0; i < total; ++i) scores[i] = total > 1 ? (float)((double)i / (double)(total - 1)) : 0.0f;
+        }
+        stats.moves_scored += total;
+        size_t m = 0;
+        for (Node* n : who) {
+            for (int k = 0; k < n->n_moves; ++k) n->move_scores[k] = scores[m++];
+            apply_tt_move(*n);
+        }
+        return 0;
+    }
+
+    // ---- open list (global_open_priority_nodes.py) ------------------------------------------
+    size_t bin_of(float score) const {
+        const float x = std::fabs(score - cfg.bin_zero_shift);
+        // np.digitize on decreasing edges: the number of edges strictly greater than x
+        size_t lo = 0, hi = bins_desc.size();
+        while (lo < hi) {
+            size_t mid = (lo + hi) / 2;
+            if (bins_desc[mid] > x) lo = mid + 1;
+            else hi = mid;
+        }
+        return lo;
+    }
+
+    void clear_bins() {
+        for (auto& b : bins) b.clear();
+        in_bins = 0;
+    }
+
+    std::vector<int> insert_and_get_batch(const std::vector<int>& ids, const std::vector<float>& scores) {
+        stats.nodes_in += ids.size();
+        std::vector<int> batch;
+        if (ids.size() + in_bins < cfg.max_batch_size) {
+            for (auto& b : bins) {
+                for (auto it = b.rbegin(); it != b.rend(); ++it)
+                    if (should_not_terminate(*it)) batch.push_back(*it);
+                b.clear();
+            }
+            in_bins = 0;
+            for (int id : ids)
+                if (should_not_terminate(id)) batch.push_back(id);
+        } else {
+            for (size_t i = 0; i < ids.size(); ++i) bins[bin_of(scores[i])].push_back(ids[i]);
+            in_bins += ids.size();
+            for (auto& b : bins) {
+                while (!b.empty() && batch.size() < cfg.max_batch_size) {
+                    const int id = b.back();
+                    b.pop_back();
+                    --in_bins;
+                    if (should_not_terminate(id)) batch.push_back(id);
+                }
+                if (batch.size() == cfg.max_batch_size) break;
+            }
+        }
+        stats.nodes_out += batch.size();
+        return batch;
+    }
+
+    // ---- one batch (do_iteration, :572-693) ------------------------------------------------
+    int iterate(const std::vector<int>& batch, std::vector<int>* to_insert, std::vector<float>* insert_scores) {
+        ++stats.iterations;
+        const size_t n = batch.size();
+        std::vector<float> parent_next_score(n);
+        // children are built at the end of the arena; the ones that stay open remain there
+        const size_t first_child = nodes.size();
+        nodes.resize(first_child + n);
+        for (size_t j = 0; j < n; ++j) {
+            Node& p = nodes[batch[j]];
+            Node& c = nodes[first_child + j];
+            const Move m = p.moves[p.next_move_index];
+            parent_next_score[j] = next_best_move(p);
+            c.b = p.b;
+            push(c.b, m);
+            c.parent = batch[j];
+            c.separator = -p.separator;
+            c.best_value = FMIN;
+            c.depth = (uint8_t)(p.depth - 1);
+            c.terminated = false;
+            c.n_moves = 0;
+            c.next_move_index = kNoMoreMoves;
+            c.children_left = 0;
+            c.prev_move = m;
+        }
+        // depth-zero children first, so that the evaluator gets its boards as early as possible
+        std::vector<int> to_eval;
+        std::vector<EvalRecord> recs;
+        for (size_t j = 0; j < n; ++j) {
+            Node& c = nodes[first_child + j];
+            if (c.depth == 0 && settle(c)) {
+                to_eval.push_back((int)j);
+                recs.emplace_back();
+                to_record(c.b, &recs.back());
+            }
+        }
+        std::vector<float> eval_scores(to_eval.size());
+        std::thread eval_thread;
+        int eval_rc = 0;
+        if (!to_eval.empty()) {
+            stats.boards_evaluated += to_eval.size();
+            stats.max_batch = std::max<uint64_t>(stats.max_batch, to_eval.size());
+            eval_thread = std::thread([&] {
+                size_t done = 0;
+                eval_rc = cfg.board_eval(cfg.eval_user, recs.data(), sizeof(EvalRecord), nullptr, recs.size(),
+                                         eval_scores.data(), &done);
+                if (!eval_rc && done != recs.size()) eval_rc = -1;
+            });
+        }
+        // meanwhile: the other children (draws, table hits, mates, move generation) and their move scores
+        std::vector<Node*> to_score;
+        for (size_t j = 0; j < n; ++j) {
+            Node& c = nodes[first_child + j];
+            if (c.depth != 0 && settle(c)) to_score.push_back(&c);
+        }
+        double wait = 0;
+        const int score_rc = score_moves(to_score, &wait);
+        if (eval_thread.joinable()) {
+            const double t0 = now();
+            eval_thread.join();
+            wait += now() - t0;
+        }
+        stats.eval_wait_seconds += wait;
+        if (eval_rc) return fail("the value network's evaluation call failed");
+        if (score_rc) return score_rc;
+        // update_tree_from_terminating_nodes, :422-453
+        size_t e = 0;
+        for (size_t j = 0; j < n; ++j) {
+            Node& c = nodes[first_child + j];
+            if (e < to_eval.size() && to_eval[e] == (int)j) {
+                const float s = eval_scores[e++] - cfg.eval_zero_shift;
+                TTEntry& t = entry(c.b.hash);  // add_evaluated_boards_to_tt, transposition_table.py:138-148
+                if (t.depth == kNoEntry) {
+                    t.hash = c.b.hash;
+                    t.depth = 0;
+                    t.lower = t.upper = s;
+                }
+                update_from_value(c.parent, -s, c.prev_move);
+            } else if (c.terminated) {
+                update_from_value(c.parent, -c.best_value, c.prev_move);
+            }
+        }
+        // parents with moves left go back to the open list, open children join it
+        to_insert->clear();
+        insert_scores->clear();
+        for (size_t j = 0; j < n; ++j)
+            if (nodes[batch[j]].next_move_index != kNoMoreMoves) {
+                to_insert->push_back(batch[j]);
+                insert_scores->push_back(parent_next_score[j]);
+            }
+        // compact the children that stay: move them down over the discarded ones
+        size_t keep = first_child;
+        for (size_t j = 0; j < n; ++j) {
+            Node& c = nodes[first_child + j];
+            if (c.depth != 0 && !c.terminated) {
+                if (keep != first_child + j) nodes[keep] = c;
+                Node& k = nodes[keep];
+                const float s = next_best_move(k);
+                to_insert->push_back((int)keep);
+                insert_scores->push_back(s);
+                ++keep;
+            }
+        }
+        nodes.resize(keep);
+        return 0;
+    }
+
+    // set_up_root_node_for_struct, :715-767
+    int make_root(const Board& start, int depth, float separator) {
+        nodes.clear();
+        clear_bins();
+        nodes.emplace_back();
+        Node& r = nodes[0];
+        r.b = start;
+        to_whites_perspective(r.b);
+        r.parent = -1;
+        r.separator = separator;
+        r.best_value = FMIN;
+        r.depth = (uint8_t)depth;
+        r.terminated = false;
+        r.n_moves = 0;
+        r.next_move_index = kNoMoreMoves;
+        r.children_left = 0;
+        r.prev_move = kNoMove;
+        if (depth == 0) {
+            // the reference never searches to depth 0; give the evaluation so callers get a value
+            if (settle(r)) {
+                EvalRecord rec;
+                to_record(r.b, &rec);
+                float s;
+                size_t done = 0;
+                if (cfg.board_eval(cfg.eval_user, &rec, sizeof rec, nullptr, 1, &s, &done) || done != 1)
+                    return fail("the value network's evaluation call failed");
+                ++stats.boards_evaluated;
+                r.best_value = s - cfg.eval_zero_shift;
+                r.terminated = true;
+            }
+            return 0;
+        }
+        if (!settle(r)) return 0;
+        double wait = 0;
+        std::vector<Node*> one{&r};
+        if (int rc = score_moves(one, &wait)) return rc;
+        stats.eval_wait_seconds += wait;
+        next_best_move(r);
+        return 0;
+    }
+
+    // zero_window_negamax_search, :696-712
+    int zero_window(const Board& start, int depth, float separator, float* value) {
+        const double t0 = now();
+        if (int rc = make_root(start, depth, separator)) return rc;
+        if (!nodes[0].terminated) {
+            std::vector<int> batch{0}, to_insert;
+            std::vector<float> scores;
+            stats.nodes_out += 1;
+            while (!batch.empty()) {
+                if (int rc = iterate(batch, &to_insert, &scores)) return rc;
+                if (nodes[0].terminated) {
+                    clear_bins();
+                    break;
+                }
+                if (to_insert.empty() && in_bins == 0) break;
+                batch = insert_and_get_batch(to_insert, scores);
+                if (nodes.size() > ((size_t)1 << 24)) return fail("search arena exceeds 2^24 nodes");
+            }
+        }
+        *value = nodes[0].best_value;
+        stats.seconds += now() - t0;
+        return 0;
+    }
+
+    // mtd_f, :778-830
+    int mtd_f(const Board& start, int depth, float first_guess, float inc, float* value, Move* move) {
+        float guess = first_guess, upper = g_win[0], lower = g_loss[0];
+        u64 root_hash = 0;
+        while (lower < upper) {
+            float beta;
+            if (lower == g_loss[0]) {
+                if (upper != g_win[0]) beta = std::min(upper - inc, std::nextafterf(upper, FMIN));
+                else beta = guess;
+            } else if (upper == g_win[0]) {
+                beta = std::max(lower + inc, std::nextafterf(lower, FMAX));
+            } else {
+                beta = std::max(lower + (upper - lower) / 2, std::nextafterf(lower, FMAX));
+            }
+            const float sep = std::nextafterf(beta, FMIN);
+            if (int rc = zero_window(start, depth, sep, &guess)) return rc;
+            root_hash = nodes[0].b.hash;
+            if (guess < beta) upper = guess;
+            else lower = guess;
+        }
+        *value = guess;
+        Move m = entry(root_hash).hash == root_hash ? entry(root_hash).move : kNoMove;  // choose_move, transposition_table.py:33-48
+        if (m.from != 255 && !start.turn) {
+            m.from ^= 56;
+            m.to ^= 56;
+        }
+        *move = m;
+        return 0;
+    }
+};
+
+// ---- C ABI -------------------------------------------------------------------------------------
+
+extern "C" const char* bfs_last_error(void) { return g_err; }
+
+extern "C" int bfs_perft(const char* fen, int depth, uint64_t* out) {
+    Board b;
+    if (!fen || !out || !board_from_fen(fen, &b)) return fail("bfs_perft: bad FEN");
+    if (depth < 0 || depth > 12) return fail("bfs_perft: depth %d out of range", depth);
+    *out = perft(b, depth);
+    return 0;
+}
+
+extern "C" int bfs_legal_moves(const char* fen, uint8_t* moves, int* n_moves) {
+    Board b;
+    if (!fen || !moves || !n_moves || !board_from_fen(fen, &b)) return fail("bfs_legal_moves: bad argument");
+    Move mv[kMaxMoves];
+    const int n = legal_moves(b, mv);
+    for (int i = 0; i < n; ++i) {
+        moves[3 * i] = mv[i].from;
+        moves[3 * i + 1] = mv[i].to;
+        moves[3 * i + 2] = mv[i].promo;
+    }
+    *n_moves = n;
+    return 0;
+}
+
+extern "C" int bfs_push(const char* fen, const uint8_t* move, char* fen_out, size_t cap) {
+    Board b;
+    if (!fen || !move || !fen_out || !board_from_fen(fen, &b)) return fail("bfs_push: bad argument");
+    const Move m{move[0], move[1], move[2]};
+    if (!is_legal(b, m)) return fail("bfs_push: illegal move %u %u %u", move[0], move[1], move[2]);
+    push(b, m);
+    if (b.hash != compute_hash(b)) return fail("bfs_push: incremental hash differs from the recomputed one");
+    const std::string s = board_to_fen(b);
+    if (s.size() + 1 > cap) return fail("bfs_push: output buffer too small");
+    std::memcpy(fen_out, s.c_str(), s.size() + 1);
+    return 0;
+}
+
+extern "C" int bfs_record_from_fen(const char* fen, void* record88) {
+    Board b;
+    if (!fen || !record88 || !board_from_fen(fen, &b)) return fail("bfs_record_from_fen: bad argument");
+    to_record(b, static_cast<EvalRecord*>(record88));
+    return 0;
+}
+
+// Random legal playout: the position after every ply, as records (legal positions for the
+// evaluation tests: SURVEY.md 8(d) "tier-2 generator").
+extern "C" int bfs_random_playout_records(const char* fen, int plies, uint64_t seed, void* records88, int* n_records) {
+    Board b;
+    if (!fen || !records88 || !n_records || !board_from_fen(fen, &b)) return fail("bfs_random_playout_records: bad argument");
+    EvalRecord* out = static_cast<EvalRecord*>(records88);
+    u64 x = seed * 0x9E3779B97F4A7C15ull + 1;
+    int n = 0;
+    for (int p = 0; p < plies; ++p) {
+        Move mv[kMaxMoves];
+        const int k = legal_moves(b, mv);
+        if (!k || b.halfmove >= 100 || insufficient_material(b)) break;
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        push(b, mv[x % (u64)k]);
+        to_record(b, &out[n++]);
+    }
+    *n_records = n;
+    return 0;
+}
+
+// bf_piece_sum_eval, code_testing.py:516-532: material in the mover's frame, the evaluator the
+// reference tests its search with.  Values per piece type P N B R Q K = 100 300 300 500 900 0.
+extern "C" int bfs_material_eval(void*, const void* records, size_t stride, const uint8_t* mask, size_t n, float* scores,
+                                 size_t* n_scored) {
+    const unsigned char* p = static_cast<const unsigned char*>(records);
+    size_t k = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (mask && !mask[i]) continue;
+        EvalRecord r;
+        std::memcpy(&r, p + i * stride, 82);
+        const u64 own = r.turn ? r.occ_white : r.occ_black, opp = r.turn ? r.occ_black : r.occ_white;
+        auto side = [&](u64 s) {
+            return 100 * __builtin_popcountll(r.pawns & s) + 300 * __builtin_popcountll((r.knights | r.bishops) & s) +
+                   500 * __builtin_popcountll(r.rooks & s) + 900 * __builtin_popcountll(r.queens & s);
+        };
+        scores[k++] = (float)(side(own) - side(opp));
+    }
+    if (n_scored) *n_scored = k;
+    return 0;
+}
+
+namespace {
+// create_negamax_function, code_testing.py:548-595: plain depth-limited negamax with the same
+// terminal rules as the search; the oracle of the zero-window property test.
+int negamax(const Board& b, int depth, float alpha, float beta, bfs_board_eval_fn eval, void* user, float* out) {
+    if (b.halfmove >= 50 || insufficient_material(b)) {
+        *out = TIE;
+        return 0;
+    }
+    Move mv[kMaxMoves];
+    const int n = legal_moves(b, mv);
+    if (!n) {
+        *out = in_check(b) ? g_loss[depth] : TIE;
+        return 0;
+    }
+    if (depth == 0) {
+        EvalRecord r;
+        to_record(b, &r);
+        size_t done = 0;
+        if (eval(user, &r, sizeof r, nullptr, 1, out, &done) || done != 1) return -1;
+        return 0;
+    }
+    float best = FMIN;
+    for (int i = 0; i < n; ++i) {
+        Board c = b;
+        push(c, mv[i]);
+        float v;
+        if (negamax(c, depth - 1, -beta, -alpha, eval, user, &v)) return -1;
+        best = std::max(best, -v);
+        alpha = std::max(alpha, best);
+        if (alpha >= beta) break;
+    }
+    *out = best;
+    return 0;
+}
+}  // namespace
+
+extern "C" int bfs_negamax(const char* fen, int depth, bfs_board_eval_fn eval, void* user, float* value) {
+    std::call_once(g_const_once, build_constants);
+    Board b;
+    if (!fen || !eval || !value || !board_from_fen(fen, &b)) return fail("bfs_negamax: bad argument");
+    if (depth < 0 || depth >= kMaxDepth) return fail("bfs_negamax: depth %d out of range", depth);
+    to_whites_perspective(b);
+    if (negamax(b, depth, FMIN, FMAX, eval, user, value)) return fail("bfs_negamax: the evaluation call failed");
+    return 0;
+}
+
+extern "C" int bfs_search_create(bfs_search** out, const bfs_config* cfg) {
+    std::call_once(g_const_once, build_constants);
+    if (!out || !cfg) return fail("bfs_search_create: null pointer");
+    *out = nullptr;
+    if (!cfg->board_eval) return fail("bfs_search_create: no evaluation function");
+    if ((cfg->move_start == nullptr) != (cfg->move_finish == nullptr)) return fail("bfs_search_create: give both move-scoring calls or neither");
+    if (cfg->max_batch_size == 0) return fail("bfs_search_create: max_batch_size is 0");
+    if (cfg->tt_bits < 4 || cfg->tt_bits > 30) return fail("bfs_search_create: tt_bits %d out of range 4..30", cfg->tt_bits);
+    if (!cfg->bin_edges || cfg->n_bin_edges == 0) return fail("bfs_search_create: no bin edges");
+    bfs_search* s = new (std::nothrow) bfs_search;
+    if (!s) return fail("bfs_search_create: out of memory");
+    s->cfg = *cfg;
+    s->bins_desc.assign(cfg->bin_edges, cfg->bin_edges + cfg->n_bin_edges);
+    std::sort(s->bins_desc.begin(), s->bins_desc.end(), [](float a, float b) { return a > b; });
+    s->cfg.bin_edges = nullptr;
+    s->bins.resize(s->bins_desc.size() + 1);
+    s->tt.assign((size_t)1 << cfg->tt_bits, TTEntry());
+    s->tt_mask = ((u64)1 << cfg->tt_bits) - 1;
+    *out = s;
+    return 0;
+}
+
+extern "C" void bfs_search_destroy(bfs_search* s) { delete s; }
+
+extern "C" void bfs_search_clear_tt(bfs_search* s) {
+    if (s) std::fill(s->tt.begin(), s->tt.end(), TTEntry());
+}
+
+extern "C" void bfs_search_stats(const bfs_search* s, bfs_stats* out, int reset) {
+    if (!s || !out) return;
+    *out = s->stats;
+    if (reset) const_cast<bfs_search*>(s)->stats = bfs_stats{};
+}
+
+extern "C" int bfs_zero_window(bfs_search* s, const char* fen, int depth, float separator, float* value) {
+    Board b;
+    if (!s || !fen || !value || !board_from_fen(fen, &b)) return fail("bfs_zero_window: bad argument");
+    if (depth < 0 || depth >= kMaxDepth) return fail("bfs_zero_window: depth %d out of range", depth);
+    // code_testing.py:606: the separator handed to the tree is the float just below the one asked for
+    return s->zero_window(b, depth, std::nextafterf(separator, FMIN), value);
+}
+
+extern "C" int bfs_mtd_f(bfs_search* s, const char* fen, int depth, float first_guess, float guess_increment, float* value,
+                         uint8_t* move) {
+    Board b;
+    if (!s || !fen || !value || !move || !board_from_fen(fen, &b)) return fail("bfs_mtd_f: bad argument");
+    if (depth < 1 || depth >= kMaxDepth) return fail("bfs_mtd_f: depth %d out of range", depth);
+    Move m;
+    if (int rc = s->mtd_f(b, depth, first_guess, guess_increment, value, &m)) return rc;
+    move[0] = m.from; move[1] = m.to; move[2] = m.promo;
+    return 0;
+}
+
+// iterative_deepening_mtd_f, :833-870 (guess increment .05 per depth, the reference's default)
+extern "C" int bfs_iterative_deepening(bfs_search* s, const char* fen, const int* depths, int n_depths, float* value,
+                                       uint8_t* move) {
+    Board b;
+    if (!s || !fen || !depths || n_depths <= 0 || !value || !move || !board_from_fen(fen, &b))
+        return fail("bfs_iterative_deepening: bad argument");
+    float guess = 0.0f;
+    Move m = kNoMove;
+    for (int i = 0; i < n_depths; ++i) {
+        if (depths[i] < 1 || depths[i] >= kMaxDepth) return fail("bfs_iterative_deepening: depth %d out of range", depths[i]);
+        if (int rc = s->mtd_f(b, depths[i], guess, 0.05f, &guess, &m)) return rc;
+    }
+    *value = guess;
+    move[0] = m.from; move[1] = m.to; move[2] = m.promo;
+    return 0;
+}

@@ -202,6 +202,10 @@ int bf_policy_check(bf_ctx* ctx, void* stream);
 int bf_policy_start_wire_host(bf_ctx* ctx, const uint8_t* h_piece_filters, size_t n_bytes,
                               const uint64_t* h_occupied_bbs, size_t n);
 
+/* The same from node records (start_move_scoring without the host encoder,
+ * numba_negamax_zero_window.py:164-180): the records selected by h_mask (nullable = all). */
+int bf_policy_start_structs_host(bf_ctx* ctx, const void* h_structs, size_t stride, const uint8_t* h_mask, size_t n);
+
 /* The closure start_move_prediction returns (chestimator.py:44-46): feed move_info =
  * (from_square, move_filter, moves_per_board), all uint8 (move_evaluation_ann.py:244-246), get one
  * float32 score per move, boards' moves back to back.  n_boards must equal the started n. */
