@@ -28,6 +28,22 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak (n
 PEAK_HBM_GBS = 8000.0
 
 
+# HBM traffic of the dominant kernel per 65 536-board launch, from the rocprofv3 PMC passes kept
+# under profiles/ (FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes; see
+# tools/pmc_summary.py).  Counters cannot be read from inside this process, so the figure is the
+# committed measurement of the same kernel and batch, not a live one.
+TRAFFIC_PROFILES = {"f32": "profiles/r1/pmc_k_eval_f32_v3.json", "bf16": "profiles/r1/pmc_k_eval_bf16_v5.json"}
+
+
+def profiled_traffic(dtype):
+    path = os.path.join(ROOT, TRAFFIC_PROFILES[dtype])
+    try:
+        with open(path) as fh:
+            return float(json.load(fh)["hbm_bytes_per_launch"]["total"]), TRAFFIC_PROFILES[dtype]
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
 def cpu_baseline(budget_s=12.0):
     """The oracle's CPU path (C encoder, single thread as the reference's serial @njit loop, then
     the torch-CPU fp32 restatement of the graph on all host cores) on a bounded sample."""
@@ -168,6 +184,7 @@ def main():
     enc_gbs = n * (88 + 3840) / (enc_ms * 1e-3) / 1e9
     del planes
 
+    traffic, traffic_src = profiled_traffic(args.dtype)
     if rank == 0:
         value = ((1 << 24) if shard else world * n) * args.steps / elapsed
         out = {
@@ -192,7 +209,8 @@ def main():
                        "parallelism": "independent shards per GPU" + (", RCCL gather of scores to rank 0" if world > 1 else "")},
             "roofline": {"bound": "mfma", "kernel": "k_eval_bf16" if bf16 else "k_eval_f32", "achieved": achieved_tflops,
                          "peak": peak_tflops, "unit": "TFLOP/s", "frac": achieved_tflops / peak_tflops,
-                         "traffic": None, "kernel_ms": kernel_ms,
+                         "traffic": traffic, "traffic_unit": "bytes per launch (HBM, PMC)", "traffic_source": traffic_src,
+                         "algorithmic_bytes": n * (32 + 4), "kernel_ms": kernel_ms,
                          "flops_per_board": spec.FLOPS_PER_BOARD},
             "encode_roofline": {"bound": "hbm", "kernel": "k_to_planes<StructSrc>", "achieved": enc_gbs,
                                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": enc_gbs / PEAK_HBM_GBS,

@@ -280,3 +280,21 @@ def test_batch_65536_properties(torch_mod, ctx, golden):
     bits = ((occ[:, None] >> torch.arange(64, device="cuda")[None, :]) & 1).to(torch.float32)
     assert torch.equal(per_square, bits)
     assert float(planes.sum()) == float(bits.sum())
+
+
+# ---- BASELINE configs[0]: 1024 random legal positions ------------------------------------------------
+
+def test_scores_on_random_legal_positions(predictor):
+    """Positions from random legal playouts (tests/golden/make_golden_legal.py): records straight to
+    the GPU, wire format through the callable, both against the oracle's scores."""
+    import os
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "legal_1024.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    structs = np.frombuffer(g["records"].tobytes(), dtype=P.COMPACT_DTYPE)
+    a = predictor.eval_structs(structs)
+    b = predictor(g["piece_filters"], g["occupied_bbs"])
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    ok32, w32 = _score_ok(a, g["scores_f32"])
+    ok64, w64 = _score_ok(a, g["scores_f64"])
+    print("legal positions: worst error / bound %.3f vs f32 oracle, %.3f vs f64 oracle" % (w32, w64))
+    assert ok32 and ok64

@@ -111,3 +111,21 @@ def test_selection_masks_and_order():
     nib, occ = E.struct_array_to_ann_inputs(a, b, ma, mb, int(ma.sum() + mb.sum()))
     nib2, occ2 = E.struct_array_to_ann_inputs(np.concatenate([a[ma], b[mb]]))
     assert np.array_equal(nib, nib2) and np.array_equal(occ, occ2)
+
+
+def test_legal_playout_fixture_is_consistent():
+    """tests/golden/legal_1024.npz: the stored wire format is what the oracle encoder makes of the
+    stored records, every board passes the reference's plane rule, and the native host encoder agrees."""
+    import os
+    from batch_first_amd import encoder, positions as P
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "legal_1024.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    structs = np.frombuffer(g["records"].tobytes(), dtype=P.COMPACT_DTYPE)
+    nib, occ = E.struct_array_to_ann_inputs(structs)
+    assert np.array_equal(nib, g["piece_filters"]) and np.array_equal(occ, g["occupied_bbs"])
+    nib2, occ2 = encoder.struct_array_to_ann_inputs(structs, structs[:0], np.ones(len(structs), bool), np.zeros(0, bool), len(structs))
+    assert np.array_equal(nib2, nib) and np.array_equal(occ2, occ)
+    planes = E.decode_planes_fast(nib, occ)
+    # kings: exactly one own king (plane 1) and one opposing king (plane 8) on every legal board
+    assert np.all(planes[:, 1].sum(axis=(1, 2)) == 1) and np.all(planes[:, 8].sum(axis=(1, 2)) == 1)
+    assert np.all(planes.sum(axis=1) <= 1)
