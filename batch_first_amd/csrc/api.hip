@@ -46,7 +46,8 @@ struct bf_ctx : Lane {               // the base is the value network's lane
     unsigned char* d_image16 = nullptr;   // bf16 image (bf_layout_bf16.h) when precision == BF_PRECISION_BF16
     // move-scoring network (bf_ctx_set_policy)
     Lane policy;
-    float* d_policy_packed = nullptr;
+    float* d_policy_packed = nullptr;          // fp32 image, or ...
+    unsigned char* d_policy_image16 = nullptr; // ... bf16 image, by the context's precision
     size_t cap_x9_boards = 0;
     float* d_x9 = nullptr;                // [boards][32][64] features of the batch in flight
     size_t policy_boards = 0;             // boards of the started, not yet finished, prediction
@@ -217,6 +218,7 @@ extern "C" void bf_ctx_destroy(bf_ctx* c) {
     if (c->d_packed) (void)hipFree(c->d_packed);
     if (c->d_image16) (void)hipFree(c->d_image16);
     if (c->d_policy_packed) (void)hipFree(c->d_policy_packed);
+    if (c->d_policy_image16) (void)hipFree(c->d_policy_image16);
     if (c->d_x9) (void)hipFree(c->d_x9);
     delete c;
 }
@@ -397,8 +399,19 @@ namespace {
 
 int check_policy(const bf_ctx* c, size_t n, const char* who) {
     if (int r = check_common(c, n, who)) return r;
-    if (!c->d_policy_packed) return bf::fail(BF_E_ARG, "%s: no move-scoring network loaded (bf_ctx_set_policy)", who);
+    if (!c->d_policy_packed && !c->d_policy_image16)
+        return bf::fail(BF_E_ARG, "%s: no move-scoring network loaded (bf_ctx_set_policy)", who);
     return BF_OK;
+}
+
+hipError_t launch_policy_features(bf_ctx* c, const uint8_t* d_mailbox, size_t n, float* d_x9, hipStream_t s) {
+    if (c->precision == BF_PRECISION_BF16) return bf::launch_policy_features_bf16(d_mailbox, n, c->d_policy_image16, d_x9, s);
+    return bf::launch_policy_features_f32(d_mailbox, n, c->d_policy_packed, d_x9, s);
+}
+
+const float* policy_logit_w(const bf_ctx* c) {
+    if (c->precision == BF_PRECISION_BF16) return reinterpret_cast<const float*>(c->d_policy_image16 + bf::b16::kOffHead);
+    return c->d_policy_packed + bf::kOffHead;
 }
 
 int ensure_x9(bf_ctx* c, size_t n) {
@@ -420,10 +433,18 @@ extern "C" int bf_ctx_set_policy(bf_ctx* c, const float* h_weights, size_t n_flo
         return bf::fail(BF_E_ARG, "bf_ctx_set_policy: expected %zu weight floats, got %zu", bf::kPolicyWeightFloats, n_floats);
     DeviceGuard guard(c->device);
     std::lock_guard<std::mutex> lock(c->policy.mu);
-    std::vector<float> packed(bf::kPackedFloats);
-    bf::pack_weights(h_weights, packed.data(), true);
-    if (!c->d_policy_packed) BF_HIP(hipMalloc(&c->d_policy_packed, bf::kPackedFloats * sizeof(float)));
-    BF_HIP(hipMemcpy(c->d_policy_packed, packed.data(), bf::kPackedFloats * sizeof(float), hipMemcpyHostToDevice));
+    BF_HIP(hipStreamSynchronize(c->policy.stream));
+    if (c->precision == BF_PRECISION_BF16) {
+        std::vector<unsigned char> image(bf::b16::kImageBytes);
+        bf::pack_weights_bf16(h_weights, image.data(), true);
+        if (!c->d_policy_image16) BF_HIP(hipMalloc(&c->d_policy_image16, image.size()));
+        BF_HIP(hipMemcpy(c->d_policy_image16, image.data(), image.size(), hipMemcpyHostToDevice));
+    } else {
+        std::vector<float> packed(bf::kPackedFloats);
+        bf::pack_weights(h_weights, packed.data(), true);
+        if (!c->d_policy_packed) BF_HIP(hipMalloc(&c->d_policy_packed, bf::kPackedFloats * sizeof(float)));
+        BF_HIP(hipMemcpy(c->d_policy_packed, packed.data(), bf::kPackedFloats * sizeof(float), hipMemcpyHostToDevice));
+    }
     c->policy_started = false;
     return BF_OK;
 }
@@ -437,7 +458,7 @@ extern "C" int bf_policy_features_wire(bf_ctx* c, const uint8_t* d_pf, size_t n_
     std::lock_guard<std::mutex> lock(c->policy.mu);
     if (int r = ensure_boards(&c->policy, n)) return r;
     BF_HIP(bf::launch_mailbox_from_wire(d_pf, n_bytes, d_occ, n, workspace(&c->policy), c->policy.d_mailbox, (hipStream_t)stream));
-    BF_HIP(bf::launch_policy_features_f32(c->policy.d_mailbox, n, c->d_policy_packed, d_x9, (hipStream_t)stream));
+    BF_HIP(launch_policy_features(c, c->policy.d_mailbox, n, d_x9, (hipStream_t)stream));
     return BF_OK;
 }
 
@@ -451,7 +472,7 @@ extern "C" int bf_policy_features_structs(bf_ctx* c, const void* d_structs, size
     std::lock_guard<std::mutex> lock(c->policy.mu);
     if (int r = ensure_boards(&c->policy, n)) return r;
     BF_HIP(bf::launch_mailbox_from_structs(d_structs, stride, n, c->policy.d_mailbox, (hipStream_t)stream));
-    BF_HIP(bf::launch_policy_features_f32(c->policy.d_mailbox, n, c->d_policy_packed, d_x9, (hipStream_t)stream));
+    BF_HIP(launch_policy_features(c, c->policy.d_mailbox, n, d_x9, (hipStream_t)stream));
     return BF_OK;
 }
 
@@ -464,7 +485,7 @@ extern "C" int bf_policy_scores(bf_ctx* c, const float* d_x9, size_t n_boards, c
     if (n_moves > ((size_t)1 << 31)) return bf::fail(BF_E_ARG, "bf_policy_scores: %zu moves exceeds the limit of 2^31", n_moves);
     if (!d_x9 || !d_board_index || !d_from || !d_filter || !d_scores) return bf::fail(BF_E_ARG, "bf_policy_scores: null pointer");
     DeviceGuard guard(c->device);
-    BF_HIP(bf::launch_policy_scores(d_x9, c->d_policy_packed, d_board_index, d_from, d_filter, n_moves, n_boards,
+    BF_HIP(bf::launch_policy_scores(d_x9, policy_logit_w(c), d_board_index, d_from, d_filter, n_moves, n_boards,
                                     c->policy.d_err, d_scores, (hipStream_t)stream));
     return BF_OK;
 }
@@ -500,7 +521,7 @@ extern "C" int bf_policy_start_wire_host(bf_ctx* c, const uint8_t* h_pf, size_t 
         BF_HIP(hipMemcpyAsync(L->d_in, L->h_in, pf_off + n_bytes, hipMemcpyHostToDevice, L->stream));
         BF_HIP(bf::launch_mailbox_from_wire(L->d_in + pf_off, n_bytes, reinterpret_cast<const uint64_t*>(L->d_in), n,
                                             workspace(L), L->d_mailbox, L->stream));
-        BF_HIP(bf::launch_policy_features_f32(L->d_mailbox, n, c->d_policy_packed, c->d_x9, L->stream));
+        BF_HIP(launch_policy_features(c, L->d_mailbox, n, c->d_x9, L->stream));
     }
     c->policy_boards = n;
     c->policy_started = true;
@@ -536,7 +557,7 @@ extern "C" int bf_policy_start_structs_host(bf_ctx* c, const void* h_structs, si
         }
         BF_HIP(hipMemcpyAsync(L->d_in, L->h_in, m * kCompact, hipMemcpyHostToDevice, L->stream));
         BF_HIP(bf::launch_mailbox_from_structs(L->d_in, kCompact, m, L->d_mailbox, L->stream));
-        BF_HIP(bf::launch_policy_features_f32(L->d_mailbox, m, c->d_policy_packed, c->d_x9, L->stream));
+        BF_HIP(launch_policy_features(c, L->d_mailbox, m, c->d_x9, L->stream));
     }
     c->policy_boards = m;
     c->policy_started = true;
@@ -579,7 +600,7 @@ extern "C" int bf_policy_finish_host(bf_ctx* c, const uint8_t* h_from, const uin
     std::memcpy(L->h_in + from_off, h_from, n_moves);
     std::memcpy(L->h_in + filter_off, h_filter, n_moves);
     BF_HIP(hipMemcpyAsync(L->d_in, L->h_in, bytes, hipMemcpyHostToDevice, L->stream));
-    BF_HIP(bf::launch_policy_scores(c->d_x9, c->d_policy_packed, reinterpret_cast<const unsigned*>(L->d_in),
+    BF_HIP(bf::launch_policy_scores(c->d_x9, policy_logit_w(c), reinterpret_cast<const unsigned*>(L->d_in),
                                     L->d_in + from_off, L->d_in + filter_off, n_moves, n_boards, L->d_err, L->d_scores,
                                     L->stream));
     BF_HIP(hipMemcpyAsync(L->h_scores, L->d_scores, n_moves * sizeof(float), hipMemcpyDeviceToHost, L->stream));

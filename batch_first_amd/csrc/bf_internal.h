@@ -14,7 +14,7 @@ const char* last_error_text();
 void pack_weights(const float* blob, float* packed, bool policy = false);
 
 // canonical blob -> bf16 image (bf_layout_bf16.h), b16::kImageBytes bytes
-void pack_weights_bf16(const float* blob, unsigned char* image);
+void pack_weights_bf16(const float* blob, unsigned char* image, bool policy = false);
 
 // Host restatement of one record's relevance mask and codes, shared by the host encoder.
 // codes_out receives popcount(mask) codes in ascending square order (mover's frame).

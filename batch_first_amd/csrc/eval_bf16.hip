@@ -324,12 +324,15 @@ __device__ __forceinline__ void conv3x3_chunk(WStream& ws, int g0, const unsigne
     }
 }
 
-template <bool DBG>
+// MODE 0: scores; 1: scores + every intermediate activation (debug); 2: features -- x9 as float32
+// [board][32][64] into `scores`, no head (the move-scoring network, see eval_f32.hip).
+template <int MODE>
 __global__ __launch_bounds__(THREADS, 1) void k_eval_bf16(const uint8_t* __restrict__ mailbox, unsigned n_boards,
                                                            const f32x4* __restrict__ wstream,
                                                            const float* __restrict__ bias,
                                                            const f32x4* __restrict__ headw,
                                                            float* __restrict__ scores, float* __restrict__ dbg) {
+    constexpr bool DBG = MODE == 1;
     __shared__ __attribute__((aligned(16))) Lds lds;
     const int tid = threadIdx.x;
     const int lane = tid & 63, hl = lane >> 5, ln = lane & 31;
@@ -506,6 +509,16 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_bf16(const uint8_t* __restr
     BF_STAMP(5);
     // ---- stage 5: 8x8 valid conv (2048 -> 16) across the workgroup's boards, ReLU, logit ------
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring's look-ahead DMA must not outlive the workgroup
+    if (MODE == 2) {
+        if (board_raw < n_boards) {
+            float* out = scores + (size_t)board * 2048;
+#pragma unroll
+            for (int T = 0; T < 2; ++T)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) out[rowmap(t, hl) * 64 + 32 * T + ln] = fmaxf(acc[T][t], 0.0f);
+        }
+        return;
+    }
     lds_order();
     write_tile(region + PLANE_BYTES + woff, R0, hl, acc[0]);   // x9 -> plane 1
     write_tile(region + PLANE_BYTES + woff + TILE1, R0, hl, acc[1]);
@@ -574,6 +587,17 @@ hipError_t launch_eval_bf16(const uint8_t* d_mailbox, size_t n, const unsigned c
     return b16::launch(d_mailbox, n, d_image, d_scores, d_debug, stream);
 }
 
+hipError_t launch_policy_features_bf16(const uint8_t* d_mailbox, size_t n, const unsigned char* d_image, float* d_x9,
+                                       hipStream_t stream) {
+    using namespace b16;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_eval_bf16<2>, dim3((unsigned)((n + BPB - 1) / BPB)), dim3(THREADS), 0, stream, d_mailbox,
+                       (unsigned)n, reinterpret_cast<const f32x4*>(d_image + b16::kOffStream),
+                       reinterpret_cast<const float*>(d_image + b16::kOffBias),
+                       reinterpret_cast<const f32x4*>(d_image + b16::kOffHead), d_x9, nullptr);
+    return hipGetLastError();
+}
+
 hipError_t b16::launch(const uint8_t* d_mailbox, size_t n, const unsigned char* d_image, float* d_scores,
                             float* d_debug, hipStream_t stream) {
     if (n == 0) return hipSuccess;
@@ -586,10 +610,10 @@ hipError_t b16::launch(const uint8_t* d_mailbox, size_t n, const unsigned char* 
 #else
     if (d_debug)
 #endif
-        hipLaunchKernelGGL(k_eval_bf16<true>, dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, (unsigned)n, ws, bias,
+        hipLaunchKernelGGL(k_eval_bf16<1>, dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, (unsigned)n, ws, bias,
                            head, d_scores, d_debug);
     else
-        hipLaunchKernelGGL(k_eval_bf16<false>, dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, (unsigned)n, ws, bias,
+        hipLaunchKernelGGL(k_eval_bf16<0>, dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, (unsigned)n, ws, bias,
                            head, d_scores, d_debug);
     return hipGetLastError();
 }

@@ -492,12 +492,12 @@ hipError_t launch_policy_features_f32(const uint8_t* d_mailbox, size_t n, const 
     return hipGetLastError();
 }
 
-hipError_t launch_policy_scores(const float* d_x9, const float* d_packed, const unsigned* d_board_index,
+hipError_t launch_policy_scores(const float* d_x9, const float* d_logit_w, const unsigned* d_board_index,
                                 const uint8_t* d_from, const uint8_t* d_filter, size_t n_moves, size_t n_boards,
                                 int* d_err, float* d_out, hipStream_t stream) {
     if (n_moves == 0 || n_boards == 0) return hipSuccess;
     hipLaunchKernelGGL(k_policy_scores, dim3((unsigned)((n_moves + 255) / 256)), dim3(256), 0, stream, d_x9,
-                       d_packed + kOffHead, d_board_index, d_from, d_filter, (unsigned)n_moves, (unsigned)n_boards,
+                       d_logit_w, d_board_index, d_from, d_filter, (unsigned)n_moves, (unsigned)n_boards,
                        d_err, d_out);
     return hipGetLastError();
 }

@@ -21,7 +21,7 @@ struct Canonical16 {
     const float* logit_w;
 };
 
-Canonical16 slice16(const float* blob) {
+Canonical16 slice16(const float* blob, bool policy) {
     Canonical16 c;
     size_t pos = 0;
     for (int i = 0; i < kNumInputConvs; ++i) {
@@ -36,6 +36,11 @@ Canonical16 slice16(const float* blob) {
     };
     bn(0, kX1Channels);
     for (int j = 0; j < 9; ++j) {
+        if (policy && j == 8) {  // the move-scoring network has no 8x8 layer (move_evaluation_ann.py:291)
+            c.tower_w[j] = nullptr;
+            c.bn_mean[j + 1] = c.bn_var[j + 1] = c.bn_beta[j + 1] = nullptr;
+            continue;
+        }
         c.tower_w[j] = blob + pos;
         pos += (size_t)kTower[j].k * kTower[j].k * kTower[j].cin * kTower[j].cout;
         bn(j + 1, kTower[j].cout);
@@ -67,13 +72,13 @@ void split3(float v, uint16_t out[3]) {
 
 }  // namespace
 
-void pack(const float* blob, unsigned char* image) {
-    const Canonical16 c = slice16(blob);
+void pack(const float* blob, unsigned char* image, bool policy) {
+    const Canonical16 c = slice16(blob, policy);
     std::memset(image, 0, kImageBytes);
 
     const int bn_ch[10] = {236, 512, 128, 32, 32, 32, 32, 32, 32, 16};
     std::vector<std::vector<float>> inv(10), shift(10);
-    for (int l = 0; l < 10; ++l) {
+    for (int l = 0; l < (policy ? 9 : 10); ++l) {
         inv[l].resize(bn_ch[l]);
         shift[l].resize(bn_ch[l]);
         for (int ch = 0; ch < bn_ch[l]; ++ch) {
@@ -86,8 +91,10 @@ void pack(const float* blob, unsigned char* image) {
     for (int ch = 0; ch < 128; ++ch) bias[kBiasX3 + ch] = shift[2][ch];
     for (int l = 0; l < 6; ++l)
         for (int ch = 0; ch < 32; ++ch) bias[kBiasX4 + 32 * l + ch] = shift[3 + l][ch];
-    for (int ch = 0; ch < 16; ++ch) bias[kBiasX10 + ch] = shift[9][ch];
-    for (int co = 0; co < 16; ++co) bias[kLogitW + co] = c.logit_w[co];
+    if (!policy) {
+        for (int ch = 0; ch < 16; ++ch) bias[kBiasX10 + ch] = shift[9][ch];
+        for (int co = 0; co < 16; ++co) bias[kLogitW + co] = c.logit_w[co];
+    }
 
     uint16_t* stream = reinterpret_cast<uint16_t*>(image + kOffStream);
     size_t group = 0;
@@ -182,6 +189,13 @@ void pack(const float* blob, unsigned char* image) {
     for (int q = 0; q < 4; ++q) conv3(c.tower_w[2], 128, q, inv[3]);
     for (int l = 0; l < 5; ++l) conv3(c.tower_w[3 + l], 32, 0, inv[4 + l]);
 
+    if (policy) {
+        // no 8x8 layer: the head region carries the logit kernel, float32 [filter][channel]
+        float* lw = reinterpret_cast<float*>(image + kOffHead);
+        for (int f = 0; f < kPolicyFilters; ++f)
+            for (int ci = 0; ci < 32; ++ci) lw[f * 32 + ci] = c.logit_w[ci * kPolicyFilters + f];
+        return;
+    }
     // ---- head: one 16x16x32 A fragment per square ------------------------------------
     uint16_t* head = reinterpret_cast<uint16_t*>(image + kOffHead);
     for (int sq = 0; sq < 64; ++sq)
@@ -194,7 +208,7 @@ void pack(const float* blob, unsigned char* image) {
 
 }  // namespace b16
 
-void pack_weights_bf16(const float* blob, unsigned char* image) { b16::pack(blob, image); }
+void pack_weights_bf16(const float* blob, unsigned char* image, bool policy) { b16::pack(blob, image, policy); }
 
 }  // namespace bf
 
@@ -206,6 +220,6 @@ extern "C" int bf_pack_weights_bf16(const float* h_weights, size_t n_floats, voi
         return bf::fail(BF_E_ARG, "bf_pack_weights_bf16: expected %zu weight floats, got %zu", bf::kWeightFloats, n_floats);
     if (n_bytes != bf::b16::kImageBytes)
         return bf::fail(BF_E_ARG, "bf_pack_weights_bf16: expected room for %zu bytes, got %zu", bf::b16::kImageBytes, n_bytes);
-    bf::pack_weights_bf16(h_weights, static_cast<unsigned char*>(h_image));
+    bf::pack_weights_bf16(h_weights, static_cast<unsigned char*>(h_image), false);
     return BF_OK;
 }

@@ -605,6 +605,25 @@ extern "C" int bfs_legal_moves(const char* fen, uint8_t* moves, int* n_moves) {
     return 0;
 }
 
+// Legal moves of a node record (bytes 0..81; the move list of a reference record is ignored).
+extern "C" int bfs_legal_moves_record(const void* record, uint8_t* moves, int* n_moves) {
+    if (!record || !moves || !n_moves) return fail("bfs_legal_moves_record: null pointer");
+    init_tables();
+    EvalRecord r;
+    std::memcpy(&r, record, 82);
+    Board b;
+    from_record(r, &b);
+    Move mv[kMaxMoves];
+    const int n = legal_moves(b, mv);
+    for (int i = 0; i < n; ++i) {
+        moves[3 * i] = mv[i].from;
+        moves[3 * i + 1] = mv[i].to;
+        moves[3 * i + 2] = mv[i].promo;
+    }
+    *n_moves = n;
+    return 0;
+}
+
 extern "C" int bfs_push(const char* fen, const uint8_t* move, char* fen_out, size_t cap) {
     Board b;
     if (!fen || !move || !fen_out || !board_from_fen(fen, &b)) return fail("bfs_push: bad argument");

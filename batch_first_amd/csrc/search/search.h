@@ -64,6 +64,7 @@ const char* bfs_last_error(void);
 // board primitives (for the perft / legality tests, code_testing.py:64-83, :266-293)
 int bfs_perft(const char* fen, int depth, uint64_t* nodes);
 int bfs_legal_moves(const char* fen, uint8_t* moves /* [100][3] */, int* n_moves);
+int bfs_legal_moves_record(const void* record82, uint8_t* moves /* [100][3] */, int* n_moves);
 int bfs_push(const char* fen, const uint8_t* move /* [3] */, char* fen_out, size_t cap);
 int bfs_record_from_fen(const char* fen, void* record88);
 int bfs_random_playout_records(const char* fen, int plies, uint64_t seed, void* records88, int* n_records);

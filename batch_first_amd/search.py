@@ -53,6 +53,8 @@ def load():
             getattr(lib, name).restype = _c.c_int
         lib.bfs_perft.argtypes = [_c.c_char_p, _c.c_int, _c.POINTER(_c.c_uint64)]
         lib.bfs_legal_moves.argtypes = [_c.c_char_p, _c.c_void_p, _c.POINTER(_c.c_int)]
+        lib.bfs_legal_moves_record.restype = _c.c_int
+        lib.bfs_legal_moves_record.argtypes = [_c.c_void_p, _c.c_void_p, _c.POINTER(_c.c_int)]
         lib.bfs_push.argtypes = [_c.c_char_p, _c.c_void_p, _c.c_char_p, _c.c_size_t]
         lib.bfs_record_from_fen.argtypes = [_c.c_char_p, _c.c_void_p]
         lib.bfs_random_playout_records.argtypes = [_c.c_char_p, _c.c_int, _c.c_uint64, _c.c_void_p, _c.POINTER(_c.c_int)]
@@ -88,6 +90,15 @@ def legal_moves(fen):
     buf = np.zeros((100, 3), np.uint8)
     n = _c.c_int(0)
     _check(load().bfs_legal_moves(fen.encode(), buf.ctypes.data, _c.byref(n)))
+    return buf[:n.value].copy()
+
+
+def legal_moves_of_record(record):
+    """Legal moves of one node record (any stride >= 82 bytes)."""
+    rec = np.ascontiguousarray(record).view(np.uint8).ravel()
+    buf = np.zeros((100, 3), np.uint8)
+    n = _c.c_int(0)
+    _check(load().bfs_legal_moves_record(rec.ctypes.data, buf.ctypes.data, _c.byref(n)))
     return buf[:n.value].copy()
 
 

@@ -185,3 +185,36 @@ def test_policy_device_ops(pweights, pgolden, golden):
         assert _ok(s.cpu().numpy(), pgolden["scores_f32"]) <= REL_TOL
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_policy_bf16_precision(pweights, pgolden, golden):
+    """BF16 context: the move-scoring network runs on the bf16 kernel (no reference counterpart;
+    bar as for the value network's bf16 precision, tests/test_gpu_bf16.py): scores within
+    5e-2 * max(|r|, rms) of the float32 oracle, and the moves of a board keep their order wherever
+    float32 separates them by more than 4x that tolerance."""
+    from batch_first_amd import chestimator
+    bp, start, closer = chestimator.get_inference_functions(W.make_weights(seed=1234, bn="perturbed"), dtype="bf16",
+                                                            policy_weights=pweights)
+    try:
+        structs = np.frombuffer(golden["records"].tobytes(), dtype=P.COMPACT_DTYPE)[:256]
+        nib, occ = E.struct_array_to_ann_inputs(structs)
+        got = start(nib, occ)([pgolden["from_squares"], pgolden["move_filters"], pgolden["moves_per_board"]])
+        again = start(nib, occ)([pgolden["from_squares"], pgolden["move_filters"], pgolden["moves_per_board"]])
+    finally:
+        closer()
+    assert np.array_equal(got.view(np.uint32), again.view(np.uint32))
+    ref = pgolden["scores_f32"]
+    worst = _ok(got, ref)
+    print("bf16 policy: worst error / rms-floored magnitude %.2e" % worst)
+    assert worst <= 5e-2
+    rms = float(np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
+    gap = 4 * 5e-2 * rms
+    pos, checked = 0, 0
+    for k in pgolden["moves_per_board"]:
+        r, g = ref[pos:pos + k].astype(np.float64), got[pos:pos + k].astype(np.float64)
+        sep = (r[:, None] - r[None, :]) > gap
+        assert np.all((g[:, None] - g[None, :])[sep] > 0)
+        checked += int(sep.sum())
+        pos += k
+    assert checked > 1000

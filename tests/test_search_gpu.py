@@ -45,3 +45,25 @@ def test_gpu_search_depth_3_statistics(predictor):
                                     st["seconds"], st["nodes_out"] / st["seconds"]))
     assert np.isfinite(value) and st["max_batch"] <= 2048
     s.close()
+
+
+def test_engine_wrapper_and_calibration(predictor):
+    """engine.py: zero-shift and bin calibration feed the search; pick_move returns a legal move."""
+    from batch_first_amd import engine, positions as P
+    recs = S.random_playout_records(FENS[0], 100, seed=11)
+    structs = np.frombuffer(recs.tobytes(), dtype=P.COMPACT_DTYPE)
+    shift = engine.calculate_eval_zero_shift(structs, predictor, max_batch_size=32)
+    assert shift.dtype == np.float32 and abs(shift - predictor.eval_structs(structs).mean()) < 1e-5
+    bins, move_shift = engine.generate_bin_ranges(structs, predictor, percentiles=np.arange(0, 100, 1.0), max_batch_size=40)
+    assert bins.shape == (100,) and np.all(np.diff(bins) >= 0) and np.isfinite(move_shift)
+    eng = engine.BatchFirstEngine(3, predictor, bins=bins, move_zero_shift=move_shift, eval_zero_shift=shift,
+                                  max_batch_size=512, tt_bits=18)
+    eng.start_new_game()
+    move, value = eng.pick_move(FENS[1])
+    assert any(np.array_equal(move, m) for m in S.legal_moves(FENS[1])) and np.isfinite(value)
+    assert len(engine.move_to_uci(move)) in (4, 5)
+    # same position again from a cleared table: same move and value (the search is deterministic)
+    eng.start_new_game()
+    move2, value2 = eng.pick_move(FENS[1])
+    assert np.array_equal(move, move2) and value == value2
+    eng.release_resources()

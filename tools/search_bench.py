@@ -59,6 +59,7 @@ def main():
            "eval_wait_fraction": total["eval_wait_seconds"] / total["seconds"], **total, "positions": rows}
     print(json.dumps({k: v for k, v in out.items() if k != "positions"}))
     if args.out:
+        os.makedirs(os.path.dirname(os.path.join(ROOT, args.out)), exist_ok=True)
         with open(os.path.join(ROOT, args.out), "w") as fh:
             json.dump(out, fh, indent=1)
 
