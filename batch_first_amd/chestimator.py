@@ -15,12 +15,15 @@ import threading
 
 import numpy as np
 
-from . import _lib, weights as _weights
+from . import _lib, graphdef as _graphdef, weights as _weights
 
 
 def _as_policy_blob(weights):
     if isinstance(weights, (str, os.PathLike)):
-        blob = np.load(os.fspath(weights))
+        if _graphdef.is_graphdef_path(weights):
+            blob = _weights.to_policy_blob(_graphdef.policy_weights(weights))
+        else:
+            blob = np.load(os.fspath(weights))
     elif isinstance(weights, dict):
         blob = _weights.to_policy_blob(weights)
     else:
@@ -52,7 +55,9 @@ def _wire_arrays(piece_filters, occupied_bbs):
 def _as_blob(weights):
     if isinstance(weights, (str, os.PathLike)):
         path = os.fspath(weights)
-        if path.endswith(".npz"):
+        if _graphdef.is_graphdef_path(path):
+            blob = _weights.to_blob(_graphdef.value_weights(path))
+        elif path.endswith(".npz"):
             with np.load(path) as z:
                 blob = z["blob"]
         else:
@@ -173,14 +178,21 @@ class BoardPredictor:
 def get_inference_functions(weights, session_gpu_memory=.4, device=0, dtype="f32", policy_weights=None):
     """(board_predictor, start_move_prediction, closer_fn), as batch_first/chestimator.py:51-74.
 
-    ``weights`` replaces ``graphdef_filename``: a ``.npy``/``.npz`` file holding the canonical
-    blob (weights.to_blob), the blob itself, or a weights dict.  ``session_gpu_memory`` is
-    accepted for call compatibility and ignored (TensorFlow's allocator fraction has no
-    counterpart here).  ``dtype``: "f32" (the parity path) or "bf16" (bf16 operands, float32 sums;
-    include/batchfirst.h, BF_PRECISION_BF16).  ``policy_weights``: the move-scoring network's blob
-    (weights.to_policy_blob), file or dict; it always runs in float32.
+    ``weights`` stands where ``graphdef_filename`` does: a frozen GraphDef file (``.pb`` binary or
+    ``.pbtxt`` text, read without TensorFlow by :mod:`batch_first_amd.graphdef`; when it also holds
+    a ``policy_network`` that one is loaded too, as the reference's single file does), a
+    ``.npy``/``.npz`` file holding the canonical blob (weights.to_blob), the blob itself, or a
+    weights dict.  ``session_gpu_memory`` is accepted for call compatibility and ignored
+    (TensorFlow's allocator fraction has no counterpart here).  ``dtype``: "f32" (the parity path)
+    or "bf16" (bf16 operands, float32 sums; include/batchfirst.h, BF_PRECISION_BF16), for both
+    networks.  ``policy_weights``: the move-scoring network's blob (weights.to_policy_blob), file
+    or dict.
     """
     del session_gpu_memory
+    if isinstance(weights, (str, os.PathLike)) and _graphdef.is_graphdef_path(weights):
+        weights, graph_policy = _graphdef.blobs_from_graphdef(weights)
+        if policy_weights is None:
+            policy_weights = graph_policy
     board_predictor = BoardPredictor(weights, device=device, dtype=dtype)
     if policy_weights is not None:
         board_predictor.set_policy(policy_weights)
