@@ -99,6 +99,7 @@ struct Lds {
     f32x4 wring[SLOTS][CHUNK][64];                       // shared A-fragment ring
     __attribute__((aligned(16))) unsigned char board[BPB][BOARD_BYTES];
     u32x4 onehot[16][2];                                 // stage 1: [code][lane half] -> 8 bf16 planes
+    __attribute__((aligned(16))) float bias3[6][2][16];  // shifts of x4..x9 in accumulator order: [layer][lane half][register]
 };
 
 // Workgroup barrier for LDS hand-offs: every LDS access of this wave has completed; global
@@ -124,39 +125,53 @@ __device__ __forceinline__ void ring_barrier() {
 
 // Lockstep walk over the A-fragment stream through the LDS ring (see eval_f32.hip).
 struct WStream {
-    const f32x4* src;
+    const unsigned char* sbase;  // wave-uniform: this wave's share of the next chunk to fetch (global memory)
+    unsigned voff;               // lane * 16
+    unsigned lds_share;          // LDS byte address of this wave's share of ring slot 0
     f32x4* ring;
-    f32x4* share;
     int rd;                // float4 offset of the slot the look-ahead reads from
     int fill;              // float4 offset of the slot being refilled
     f32x4 pre[LA + 1];
 
     // LDS-DMA: one 1-KiB piece of this wave's share straight from L2 into a ring slot, lane-linear.
-    // Issued as inline asm on purpose: the compiler models global_load_lds as a FLAT access that
-    // may touch LDS, and while one is outstanding it turns every LDS wait into lgkmcnt(0), which
-    // stalls each group of MFMAs on the read just issued.  ring_barrier() does the vmcnt
-    // bookkeeping instead; ordinary loads interleaved by the compiler only make its own vmcnt
-    // waits stricter (vector-memory operations retire in order).
-    // Issuing a piece holds the wave for 60+ cycles, so the SHARE pieces of a refill are spread over
-    // the first SHARE groups after the chunk barrier: each one issues while the two MFMAs of the
-    // previous group execute.
-    __device__ __forceinline__ void fetch_piece(int slot_off, int i) {
-        typedef __attribute__((address_space(3))) f32x4* lds_ptr;
-        const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr)(share + slot_off);
+    // One instruction per piece: global address = scalar base + lane * 16 + immediate, LDS address
+    // = M0 + immediate + lane * 16 (the instruction's immediate offset applies to both sides), so
+    // M0 and the scalar base are set once per chunk (set_m0, and the advance after the last piece)
+    // and the SHARE pieces differ in their immediates only.  Measured (tools/issue_rate.hip,
+    // tools/dma_issue_cost.hip): with one wave per SIMD every scalar ALU instruction in an MFMA gap
+    // costs 8 cycles of issue and the piece itself next to nothing, so the earlier form (64-bit
+    // address arithmetic + s_mov m0 + s_nop per piece) cost more than the load.
+    // Inline asm on purpose: the compiler models global_load_lds as a FLAT access that may touch
+    // LDS, and while one is outstanding it turns every LDS wait into lgkmcnt(0), which stalls each
+    // group of MFMAs on the read just issued.  ring_barrier() does the vmcnt bookkeeping instead;
+    // ordinary loads interleaved by the compiler only make its own vmcnt waits stricter
+    // (vector-memory operations retire in order).  M0 is not written by anything else in this
+    // kernel (no dynamic register indexing, no other LDS-DMA, no GWS).
+    __device__ __forceinline__ void set_m0(int slot_off) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(lds_share + (unsigned)slot_off * 16u) : "memory", "m0");
+    }
+    __device__ __forceinline__ void fetch_piece(int i) {
+        static_assert(SHARE <= 4, "immediate offsets of a global instruction reach 4095");
 #ifndef BF16_ABL_NODMA
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
-                     :: "s"(lds0 + i * 1024), "v"(src + i * 64) : "memory", "m0");
+        if (i == 0) asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase) : "memory");
+        if (i == 1) asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" ::"v"(voff), "s"(sbase) : "memory");
+        if (i == 2) asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" ::"v"(voff), "s"(sbase) : "memory");
+        if (i == 3) asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" ::"v"(voff), "s"(sbase) : "memory");
 #endif
-        if (i == SHARE - 1) src += CHUNK * 64;
+        if (i == SHARE - 1) sbase += CHUNK * 1024;
     }
     __device__ __forceinline__ void prime(const f32x4* stream, f32x4* ring_base, int lane, int wave) {
+        typedef __attribute__((address_space(3))) f32x4* lds_ptr;
         ring = ring_base + lane;
-        share = ring_base + wave * SHARE * 64;
-        src = stream + wave * SHARE * 64 + lane;
+        lds_share = (unsigned)(uintptr_t)(lds_ptr)(ring_base + wave * SHARE * 64);
+        sbase = reinterpret_cast<const unsigned char*>(stream + wave * SHARE * 64);
+        voff = (unsigned)lane * 16u;
 #pragma unroll
-        for (int c = 0; c < SLOTS - 2; ++c)
+        for (int c = 0; c < SLOTS - 2; ++c) {
+            set_m0(c * CHUNK * 64);
 #pragma unroll
-            for (int i = 0; i < SHARE; ++i) fetch_piece(c * CHUNK * 64, i);
+            for (int i = 0; i < SHARE; ++i) fetch_piece(i);
+        }
         rd = (SLOTS - 1) * CHUNK * 64;
     }
     // After the barrier every wave's share of chunk k is in LDS and nobody reads chunk k-2 any
@@ -167,13 +182,14 @@ struct WStream {
         if (fill >= SLOTS * CHUNK * 64) fill -= SLOTS * CHUNK * 64;
         __builtin_amdgcn_sched_barrier(0);
         ring_barrier();
+        set_m0(fill);
         __builtin_amdgcn_sched_barrier(0);
     }
     __device__ __forceinline__ void start() {
         next_chunk();
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
-            if (i < SHARE) fetch_piece(fill, i);
+            if (i < SHARE) fetch_piece(i);
             pre[i] = ring[rd + i * 64];
         }
     }
@@ -181,7 +197,7 @@ struct WStream {
     __device__ __forceinline__ bf16x8 take(int g) {
         const int nx = g + LA, i = nx % CHUNK;
         if (i == 0) next_chunk();
-        if (i < SHARE) fetch_piece(fill, i);
+        if (i < SHARE) fetch_piece(i);
 #ifndef BF16_ABL_NOAREAD
         pre[nx % (LA + 1)] = ring[rd + i * 64];
 #endif
@@ -228,64 +244,114 @@ __device__ __forceinline__ f32x16 zero16() {
 // through another vector type (the hardware keeps a wave's LDS accesses in order).
 __device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
 
-// Stage 1, one input conv for both tiles.  reference: ann_creation_helper.py:211-236 (SAME padding:
-// (k-1)*d in total, floor(/2) before).  mbc: tile 0's square of this lane in the byte mailbox
-// (tile 1: 4 ranks up); tbl: the one-hot table at this lane's half.
-template <int I, bool DBG>
-__device__ __forceinline__ void input_conv(WStream& ws, const unsigned char* mbc, const u32x4* tbl,
-                                           unsigned (&P)[2][kX1Dwords], int hl, int ln, float* dbg_board) {
-    constexpr InputConv cv = kInputConvs[I];
-    constexpr int G0 = input_group_base(I);
-    constexpr int ph = ((cv.k - 1) * cv.dh) / 2, pw = ((cv.k - 1) * cv.dw) / 2;
-    constexpr int TAPS = cv.k * cv.k;
-    int code[2][TAPS];
-#pragma unroll
-    for (int T = 0; T < 2; ++T)
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
+// Stage 1 as one flat list of (conv, tap) steps.  reference: ann_creation_helper.py:211-236 (SAME
+// padding: (k-1)*d in total, floor(/2) before).
+struct S1Table {
+    int conv[96], tap[96], off[96][2], group0[96], first_step[kNumInputConvs + 1];
+    int steps;
+};
+constexpr S1Table make_s1_table() {
+    S1Table t{};
+    int k = 0, g = 0;
+    for (int i = 0; i < kNumInputConvs; ++i) {
+        const InputConv cv = kInputConvs[i];
+        const int ph = ((cv.k - 1) * cv.dh) / 2, pw = ((cv.k - 1) * cv.dw) / 2;
+        t.first_step[i] = k;
+        for (int tap = 0; tap < cv.k * cv.k; ++tap, ++k) {
             const int dr = (tap / cv.k) * cv.dh - ph, df = (tap % cv.k) * cv.dw - pw;
-            code[T][tap] = mbc[(4 * T + dr) * MB_W + df];
+            t.conv[k] = i;
+            t.tap[k] = tap;
+            t.off[k][0] = dr * MB_W + df;            // tile 0's square of this lane
+            t.off[k][1] = (4 + dr) * MB_W + df;      // tile 1: 4 ranks up
+            t.group0[k] = g;
+            g += cv.tiles;
         }
-    u32x4 b[2][TAPS];
-#pragma unroll
-    for (int T = 0; T < 2; ++T)
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) b[T][tap] = tbl[code[T][tap] * 2];
-    f32x16 acc[2][cv.tiles];
-#pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap)
-#pragma unroll
-        for (int tile = 0; tile < cv.tiles; ++tile) {
-            const bf16x8 w = ws.take(G0 + tap * cv.tiles + tile);
-#pragma unroll
-            for (int T = 0; T < 2; ++T)
-                acc[T][tile] = BF_MFMA16(w, __builtin_bit_cast(bf16x8, b[T][tap]), tap == 0 ? zero16() : acc[T][tile]);
-        }
-#pragma unroll
-    for (int T = 0; T < 2; ++T)
-#pragma unroll
-        for (int d = 0; d < kX1RegCount[I] / 2; ++d) {
-            const int tile = (2 * d) / 16, t = (2 * d) % 16;
-            const unsigned p = pack_relu(acc[T][tile][t], acc[T][tile][t + 1]);
-            P[T][kX1RegBase[I] / 2 + d] = p;
-            if (DBG) {
-                const int c0 = 2 * (2 * d) + hl, c1 = 2 * (2 * d + 1) + hl;  // local channels of the pair
-                if (c0 < cv.ch) dbg_board[(cv.chan_base + c0) * 64 + 32 * T + ln] = bf16_lo(p);
-                if (c1 < cv.ch) dbg_board[(cv.chan_base + c1) * 64 + 32 * T + ln] = bf16_hi(p);
-            }
-        }
+    }
+    t.first_step[kNumInputConvs] = k;
+    t.steps = k;
+    for (int j = k; j < 96; ++j) {  // look-ahead past the end re-reads the last step (harmless)
+        t.conv[j] = kNumInputConvs - 1;
+        t.tap[j] = 0;
+        t.off[j][0] = t.off[k - 1][0];
+        t.off[j][1] = t.off[k - 1][1];
+        t.group0[j] = g;
+    }
+    return t;
+}
+constexpr S1Table kS1 = make_s1_table();
+static_assert(kS1.steps == 71 && kS1.group0[70] + 1 == kInputGroups, "");
+
+// ReLU + bf16 of the finished accumulators of input conv I, piece by piece (one piece = one packed
+// dword of one tile), so that the pieces can ride in the MFMA gaps of the next conv.
+template <bool DBG>
+__device__ __forceinline__ void s1_pack_piece(int I, int piece, const f32x16 (&acc)[2][2], unsigned (&P)[2][kX1Dwords], int hl,
+                                              int ln, float* dbg_board) {
+    const int half = kX1RegCount[I] / 2;
+    const int T = piece / half, d = piece % half;
+    const int tile = (2 * d) / 16, t = (2 * d) % 16;
+    const unsigned p = pack_relu(acc[T][tile][t], acc[T][tile][t + 1]);
+    P[T][kX1RegBase[I] / 2 + d] = p;
+    if (DBG) {
+        const int c0 = 2 * (2 * d) + hl, c1 = 2 * (2 * d + 1) + hl;  // local channels of the pair
+        if (c0 < kInputConvs[I].ch) dbg_board[(kInputConvs[I].chan_base + c0) * 64 + 32 * T + ln] = bf16_lo(p);
+        if (c1 < kInputConvs[I].ch) dbg_board[(kInputConvs[I].chan_base + c1) * 64 + 32 * T + ln] = bf16_hi(p);
+    }
 }
 
-// ReLU + bf16 of one accumulator tile into this lane's position of a plane: registers 4g..4g+3
-// are channels 8g + 4hl .. +3, i.e. 8 bytes at channel chunk g.
-__device__ __forceinline__ void write_tile(unsigned char* wpos, int R0, int hl, const f32x16& a) {
+// The B operand of a step is found in two dependent LDS reads (code byte of the shifted square,
+// then that code's one-hot row), so both run ahead of the MFMAs: codes CQ + BQ steps, rows BQ
+// steps.  The ReLU + pack of conv I rides in the gaps of conv I+1 (its last MFMA is then at least
+// two steps old), at most 4 pieces per group.  mbc: tile 0's square of this lane in the byte
+// mailbox; tbl: the one-hot table at this lane's half.
+template <bool DBG>
+__device__ __forceinline__ void stage1(WStream& ws, const unsigned char* mbc, const u32x4* tbl, unsigned (&P)[2][kX1Dwords],
+                                       int hl, int ln, float* dbg_board) {
+    constexpr int CQ = 2, BQ = 2, NC = CQ + BQ;
+    int code[NC][2];
+    u32x4 b[BQ][2];
+    f32x16 acc[2][2][2];  // [conv parity][board tile][channel tile]
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        u32x2 v;
-        v.x = pack_relu(a[4 * g + 0], a[4 * g + 1]);
-        v.y = pack_relu(a[4 * g + 2], a[4 * g + 3]);
-        *reinterpret_cast<u32x2*>(wpos + (((g + R0) & 3) << 4) + hl * 8) = v;
+    for (int k = 0; k < NC; ++k)
+#pragma unroll
+        for (int T = 0; T < 2; ++T) code[k][T] = mbc[kS1.off[k][T]];
+#pragma unroll
+    for (int k = 0; k < BQ; ++k)
+#pragma unroll
+        for (int T = 0; T < 2; ++T) b[k][T] = tbl[code[k][T] * 2];
+#pragma unroll
+    for (int k = 0; k < kS1.steps; ++k) {
+        const int I = kS1.conv[k], tap = kS1.tap[k], par = I & 1;
+        const int tiles = kInputConvs[I].tiles;
+        u32x4 bk[2] = {b[k % BQ][0], b[k % BQ][1]};
+#pragma unroll
+        for (int tile = 0; tile < 2; ++tile) {
+            if (tile >= tiles) continue;
+            const bf16x8 w = ws.take(kS1.group0[k] + tile);
+#pragma unroll
+            for (int T = 0; T < 2; ++T)
+                acc[par][T][tile] = BF_MFMA16(w, __builtin_bit_cast(bf16x8, bk[T]), tap == 0 ? zero16() : acc[par][T][tile]);
+            if (tile == 0) {
+                // rows for step k+BQ (their codes were read CQ steps ago), codes for step k+NC
+#pragma unroll
+                for (int T = 0; T < 2; ++T) b[k % BQ][T] = tbl[code[(k + BQ) % NC][T] * 2];
+#pragma unroll
+                for (int T = 0; T < 2; ++T) code[k % NC][T] = mbc[kS1.off[k + NC][T]];
+            }
+            if (I > 0) {
+                const int j = tap * tiles + tile;  // group of this conv
+                const int total = kX1RegCount[I - 1];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int piece = 4 * (j - 1) + q;
+                    if (j >= 1 && piece < total) s1_pack_piece<DBG>(I - 1, piece, acc[par ^ 1], P, hl, ln, dbg_board);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
+#pragma unroll
+    for (int piece = 0; piece < kX1RegCount[kNumInputConvs - 1]; ++piece)
+        s1_pack_piece<DBG>(kNumInputConvs - 1, piece, acc[(kNumInputConvs - 1) & 1], P, hl, ln, dbg_board);
 }
 
 // Debug dump of a tile as the bf16 values the next layer sees.
@@ -295,32 +361,6 @@ __device__ __forceinline__ void dump_tile(float* dst_ch0, int hl, int sq, const 
         const unsigned p = pack_relu(a[t], a[t + 1]);
         dst_ch0[rowmap(t, hl) * 64 + sq] = bf16_lo(p);
         dst_ch0[rowmap(t + 1, hl) * 64 + sq] = bf16_hi(p);
-    }
-}
-
-// One 3x3 SAME conv over a 32-channel chunk staged in a plane, both tiles: 9 taps x 2 k-steps.
-// raddr[dr][s]: byte offset (in the plane) of tile 0's chunk 2s+hl one row and column back, dr rows down.
-__device__ __forceinline__ void conv3x3_chunk(WStream& ws, int g0, const unsigned char* plane, const int (&raddr)[3][2],
-                                              f32x16 (&acc)[2]) {
-    auto load_b = [&](int idx, int T) -> u32x4 {
-        const int tap = idx >> 1, s = idx & 1;
-        return *reinterpret_cast<const u32x4*>(plane + raddr[tap / 3][s] + T * TILE1 + (tap % 3) * POS_BYTES);
-    };
-    u32x4 b[3][2];
-#pragma unroll
-    for (int T = 0; T < 2; ++T) {
-        b[0][T] = load_b(0, T);
-        b[1][T] = load_b(1, T);
-    }
-#pragma unroll
-    for (int idx = 0; idx < 18; ++idx) {
-        if (idx + 2 < 18) {
-            b[(idx + 2) % 3][0] = load_b(idx + 2, 0);
-            b[(idx + 2) % 3][1] = load_b(idx + 2, 1);
-        }
-        const bf16x8 w = ws.take(g0 + idx);
-        acc[0] = BF_MFMA16(w, __builtin_bit_cast(bf16x8, b[idx % 3][0]), acc[0]);
-        acc[1] = BF_MFMA16(w, __builtin_bit_cast(bf16x8, b[idx % 3][1]), acc[1]);
     }
 }
 
@@ -345,6 +385,9 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_bf16(const uint8_t* __restr
     long long stamps[16];
 #endif
     BF_STAMP(0);
+#ifdef BF_STAMPS
+    if (lane == 0) stamps[7] = __builtin_amdgcn_s_memrealtime();  // constant 100 MHz clock, common to the chip
+#endif
     WStream ws;
     ws.prime(wstream, &lds.wring[0][0][0], lane, wave);
 
@@ -361,13 +404,16 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_bf16(const uint8_t* __restr
         e.w |= ((j >> 1) == 3u) ? one : 0u;
         lds.onehot[c][hh] = e;
     }
+    for (int i = tid; i < 6 * 32; i += THREADS)
+        lds.bias3[i >> 5][(i >> 4) & 1][i & 15] = bias[kBiasX4 + 32 * (i >> 5) + rowmap(i & 15, (i >> 4) & 1)];
     lds_order();
     {
         const unsigned v = mailbox[(size_t)board * kMailboxBytes + (lane >> 1)];
         const unsigned c = (lane & 1) ? (v >> 4) : (v & 15u);
         region[((lane >> 3) + 7) * MB_W + (lane & 7) + 7] = (unsigned char)c;
     }
-    ws.start();  // its barrier also orders the table writes before stage 1 reads them
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the table writes have reached LDS ...
+    ws.start();  // ... before its barrier lets stage 1 of any wave read them
 
     float* dbg_board = DBG ? dbg + (size_t)board * kDebugFloatsPerBoard : nullptr;
     BF_STAMP(1);
@@ -377,15 +423,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_bf16(const uint8_t* __restr
     {
         const unsigned char* mbc = region + (rank + 7) * MB_W + file + 7;
         const u32x4* tbl = &lds.onehot[0][hl];
-        input_conv<0, DBG>(ws, mbc, tbl, P, hl, ln, dbg_board);
-        input_conv<1, DBG>(ws, mbc, tbl, P, hl, ln, dbg_board);
-        input_conv<2, DBG>(ws, mbc, tbl, P, hl, ln, dbg_board);
-        input_conv<3, DBG>(ws, mbc, tbl, P, hl, ln, dbg_board);
-        input_conv<4, DBG>(ws, mbc, tbl, P, hl, ln, dbg_board);
-        input_conv<5, DBG>(ws, mbc, tbl, P, hl, ln, dbg_board);
-        input_conv<6, DBG>(ws, mbc, tbl, P, hl, ln, dbg_board);
-        input_conv<7, DBG>(ws, mbc, tbl, P, hl, ln, dbg_board);
-        input_conv<8, DBG>(ws, mbc, tbl, P, hl, ln, dbg_board);
+        stage1<DBG>(ws, mbc, tbl, P, hl, ln, dbg_board);
     }
     // The byte mailbox is dead (only this wave reads it): its space becomes the two zero-haloed planes.
     lds_order();
@@ -461,6 +499,16 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_bf16(const uint8_t* __restr
 
     BF_STAMP(3);
     // ---- stages 3 and 4: the six 3x3 layers through the wave's own planes ------------------
+    // One flat list of 9 x 36 MFMA slots: chunk c = 0..3 are the four 32-channel input chunks of
+    // the 128->32 layer, c = 4..8 the five 32->32 layers; chunk c reads plane c & 1.  A layer
+    // needs the whole previous layer, so with one wave per SIMD a layer-by-layer walk leaves the
+    // matrix pipe idle for every ReLU + pack -> LDS write -> shifted read chain.  Instead the two
+    // tiles of chunks 3..8 run skewed: tile 0 first (its 18 fragments stay in registers for tile
+    // 1), so that tile 0's result is packed and written while tile 1 multiplies, and tile 1's while
+    // the next layer's tile 0 runs its taps of the two upper rows (dr = -1, 0), which read tile 0's
+    // ranks only.  Chunks 0..2 have all their input from the start: both tiles share each fragment
+    // as it arrives and the next chunk's input is written in their gaps.  Shifts come from LDS
+    // (lds.bias3) as the C operand of a layer's first MFMAs; B operands are read D slots ahead.
     const int R0 = rank + 1;                                // padded row of tile 0's square (tile 1: +4, same & 3)
     const int woff = (R0 * XP_W + file + 1) * POS_BYTES;    // tile 0's square; tile 1 at + TILE1
     int raddr[3][2];
@@ -470,41 +518,80 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_bf16(const uint8_t* __restr
         for (int s = 0; s < 2; ++s)
             raddr[dr][s] = ((rank + dr) * XP_W + file) * POS_BYTES + (((2 * s + hl + rank + dr) & 3) << 4);
 
-    f32x16 acc[2];
+    // ReLU + bf16 of registers 4g..4g+3 of a tile (channels 8g + 4hl .. +3) into this lane's
+    // position of plane `pl`: 8 bytes at channel chunk g, chunk position rotated by the padded row.
+    auto write_piece = [&](int pl, int T, int g, const f32x16& a) {
+        u32x2 v;
+        v.x = pack_relu(a[4 * g + 0], a[4 * g + 1]);
+        v.y = pack_relu(a[4 * g + 2], a[4 * g + 3]);
+        lds_order();
+        *reinterpret_cast<u32x2*>(region + pl * PLANE_BYTES + woff + T * TILE1 + (((g + R0) & 3) << 4) + hl * 8) = v;
+        lds_order();
+    };
+    // slot n -> chunk, tile, (tap, k-step) index
+    auto slot_c = [](int n) { return n / 36; };
+    auto slot_T = [](int n) { return (n / 36) < 3 ? (n % 36) & 1 : (n % 36) / 18; };
+    auto slot_idx = [](int n) { return (n / 36) < 3 ? (n % 36) >> 1 : (n % 36) % 18; };
+    auto load_b = [&](int n) -> u32x4 {
+        const int c = slot_c(n), T = slot_T(n), idx = slot_idx(n);
+        const int tap = idx >> 1, s = idx & 1;
+        return *reinterpret_cast<const u32x4*>(region + (c & 1) * PLANE_BYTES + raddr[tap / 3][s] + T * TILE1 + (tap % 3) * POS_BYTES);
+    };
+    constexpr int D = 4, NSLOTS = 9 * 36;
+    // Head kernels of this wave's squares (stage 5), fetched during the last but one layer so that their
+    // L2 latency is not exposed after the last MFMA: 16 plain loads right after a ring barrier (the next
+    // barrier's counted vmcnt then covers them too, 16 groups later).
+    constexpr int SQW = 64 / WAVES;  // squares (k-steps of the head) per wave
+    u32x4 ha[SQW];
+    const f32x4* hwp = headw + (size_t)wave * SQW * 64 + lane;
+    f32x16 A[2][2];   // [set][tile]: chunks 0..3 accumulate in set 0, layer c >= 4 in set (c & 1) ^ 1
+    f32x16 bs;        // shift of the layer about to start
+    u32x4 bq[D];
+    bf16x8 f[18];
+    bf16x8 wj{};
+    auto load_bias = [&](int l, int i) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&lds.bias3[l][hl][4 * i]);
+        bs[4 * i] = v.x; bs[4 * i + 1] = v.y; bs[4 * i + 2] = v.z; bs[4 * i + 3] = v.w;
+    };
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        acc[0][t] = pick(hl, bias[kBiasX4 + rowmap(t, 0)], bias[kBiasX4 + rowmap(t, 1)]);
-        acc[1][t] = acc[0][t];
-    }
+    for (int p = 0; p < 8; ++p) write_piece(0, p >> 2, p & 3, acc3[p >> 2][0]);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        unsigned char* plane = region + (q & 1) * PLANE_BYTES;
-        lds_order();
-        write_tile(plane + woff, R0, hl, acc3[0][q]);
-        write_tile(plane + woff + TILE1, R0, hl, acc3[1][q]);
-        lds_order();
-        conv3x3_chunk(ws, kConvBase + q * 18, plane, raddr, acc);
-    }
-    BF_STAMP(4);
+    for (int i = 0; i < 4; ++i) load_bias(0, i);
 #pragma unroll
-    for (int layer = 0; layer < 5; ++layer) {
-        unsigned char* plane = region + (layer & 1) * PLANE_BYTES;
-        lds_order();
-        write_tile(plane + woff, R0, hl, acc[0]);
-        write_tile(plane + woff + TILE1, R0, hl, acc[1]);
-        lds_order();
-        if (DBG) {
-            dump_tile(dbg_board + 64 * (236 + 128 + 32 * layer), hl, ln, acc[0]);
-            dump_tile(dbg_board + 64 * (236 + 128 + 32 * layer), hl, 32 + ln, acc[1]);
+    for (int n = 0; n < D; ++n) bq[n] = load_b(n);
+#pragma unroll
+    for (int n = 0; n < NSLOTS; ++n) {
+        const int c = slot_c(n), r = n % 36, T = slot_T(n), idx = slot_idx(n);
+        if (n == 4 * 36) BF_STAMP(4);
+        if (MODE != 2 && n == 7 * 36 + 12) {
+#pragma unroll
+            for (int i = 0; i < SQW; ++i) ha[i] = __builtin_bit_cast(u32x4, hwp[i * 64]);
         }
-        const float* bl = bias + kBiasX4 + 32 * (layer + 1);
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            acc[0][t] = pick(hl, bl[rowmap(t, 0)], bl[rowmap(t, 1)]);
-            acc[1][t] = acc[0][t];
+        const bool joint = c < 3;
+        const int o = c <= 3 ? 0 : ((c & 1) ^ 1);
+        bf16x8 w;
+        if (T == 0) {
+            w = ws.take(kConvBase + c * 18 + idx);
+            if (joint) wj = w; else f[idx] = w;
+        } else {
+            w = joint ? wj : f[idx];
         }
-        conv3x3_chunk(ws, kConvBase + kConv4Groups + layer * 18, plane, raddr, acc);
+        const bool fresh = idx == 0 && (c == 0 || c >= 4);
+        A[o][T] = BF_MFMA16(w, __builtin_bit_cast(bf16x8, bq[n % D]), fresh ? bs : A[o][T]);
+        if (n + D < NSLOTS) bq[n % D] = load_b(n + D);
+        if (joint) {
+            // input of chunk c+1 (plane (c+1) & 1; chunk c-1's reads of it were issued long ago)
+            if (r >= 2 && r <= 16 && (r & 1) == 0) write_piece((c + 1) & 1, (r - 2) >> 3, ((r - 2) >> 1) & 3, acc3[(r - 2) >> 3][c + 1]);
+        } else {
+            if (c < 8 && r >= 20 && r < 24) write_piece((c + 1) & 1, 0, r - 20, A[o][0]);   // tile 0 of x(c+1)
+            if (c < 8 && r >= 26 && r < 30) load_bias(c + 1 - 3, r - 26);
+            if (c >= 4 && r >= 2 && r < 6) write_piece(c & 1, 1, r - 2, A[o ^ 1][1]);      // tile 1 of this layer's input
+            if (DBG && c < 8 && r == 20) dump_tile(dbg_board + 64 * (236 + 128 + 32 * (c - 3)), hl, ln, A[o][0]);
+            if (DBG && c >= 4 && r == 2) dump_tile(dbg_board + 64 * (236 + 128 + 32 * (c - 4)), hl, 32 + ln, A[o ^ 1][1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
+    f32x16 (&acc)[2] = A[1];  // x9 before its ReLU
 
     BF_STAMP(5);
     // ---- stage 5: 8x8 valid conv (2048 -> 16) across the workgroup's boards, ReLU, logit ------
@@ -520,18 +607,13 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_bf16(const uint8_t* __restr
         return;
     }
     lds_order();
-    write_tile(region + PLANE_BYTES + woff, R0, hl, acc[0]);   // x9 -> plane 1
-    write_tile(region + PLANE_BYTES + woff + TILE1, R0, hl, acc[1]);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) write_piece(1, p >> 2, p & 3, acc[p >> 2]);   // x9 -> plane 1
     if (DBG) {
         dump_tile(dbg_board + 64 * (236 + 128 + 32 * 5), hl, ln, acc[0]);
         dump_tile(dbg_board + 64 * (236 + 128 + 32 * 5), hl, 32 + ln, acc[1]);
     }
-    constexpr int SQW = 64 / WAVES;  // squares (k-steps) per wave
     const int col = lane & 15, kc = lane >> 4;
-    u32x4 ha[SQW];
-#pragma unroll
-    for (int i = 0; i < SQW; ++i)
-        ha[i] = __builtin_bit_cast(u32x4, headw[(size_t)(wave * SQW + i) * 64 + lane]);
     __syncthreads();
     {
         const unsigned char* xb = lds.board[col < BPB ? col : 0] + PLANE_BYTES;
@@ -567,10 +649,10 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_bf16(const uint8_t* __restr
     }
 #ifdef BF_STAMPS
     BF_STAMP(6);
+    if (lane == 0) stamps[14] = __builtin_amdgcn_s_memrealtime();
     if (!DBG && dbg && lane == 0) {
         long long* out = reinterpret_cast<long long*>(dbg) + ((size_t)blockIdx.x * WAVES + wave) * 16;
-        for (int i = 0; i < 7; ++i) out[i] = stamps[i];
-        for (int i = 8; i < 14; ++i) out[i] = stamps[i];
+        for (int i = 0; i < 15; ++i) out[i] = stamps[i];
     }
 #endif
 }

@@ -38,3 +38,9 @@ print("kernel span (stamp ticks)", span, " sum of wave lives / span = average wa
 ph = np.diff(raw[:, :, 8:14], axis=2)
 for i, nm in enumerate(["A G1 t0 (480)", "B G1 t1 (480)", "C G2 t0 (256)", "D G2 t1 (256)", "next tile (1472)"]):
     print("%-18s median %7.0f p10 %7.0f p90 %7.0f" % (nm, np.median(ph[:, :, i]), np.percentile(ph[:, :, i], 10), np.percentile(ph[:, :, i], 90)))
+rt0, rt1 = raw[:, :, 7], raw[:, :, 14]
+rt_life = (rt1 - rt0).astype(np.float64)
+ok = rt_life > 0
+print("stamp ticks per 100 MHz tick: median %.2f  => stamp clock %.3f GHz" % (np.median(life[ok] / rt_life[ok]), np.median(life[ok] / rt_life[ok]) * 0.1))
+span_rt = rt1.max() - rt0.min()
+print("kernel span %.1f us (100 MHz clock); sum of wave lives / (span * 1024 SIMDs) = %.3f" % (span_rt / 100.0, rt_life.sum() / (span_rt * 1024.0)))
