@@ -56,8 +56,13 @@ constexpr int kGemmBase = kInputGroups;
 constexpr int kConvBase = kGemmBase + kC2Tiles * kPerC2Groups;          // 464
 constexpr int kStreamGroups = kConvBase + kConv4Groups + kConv59Groups;  // 626
 constexpr int kStreamChunkMax = 16;
-constexpr int kStreamPadGroups = 3 * kStreamChunkMax + 14;  // prefetch overrun; total 688 = 43 * 16
-constexpr size_t kStreamBytes = (size_t)(kStreamGroups + kStreamPadGroups) * kGroupBytes;
+// The kernel walks the stream as a ring, board after board: padded to 640 groups = 40 chunks of 16,
+// a multiple of the ring's slot count and of the register look-ahead, so that every board starts in
+// the same ring phase; the prefetch wraps to group 0 instead of running past the end.
+constexpr int kStreamPadGroups = 14;
+constexpr int kStreamWalkGroups = kStreamGroups + kStreamPadGroups;  // 640
+static_assert(kStreamWalkGroups % kStreamChunkMax == 0, "");
+constexpr size_t kStreamBytes = (size_t)kStreamWalkGroups * kGroupBytes;
 
 // float32 shifts that initialise accumulators: x3 (128), x4..x9 (6 x 32), x10 (16), logit weights (16)
 constexpr int kBiasX3 = 0, kBiasX4 = 128, kBiasX10 = 128 + 192, kLogitW = kBiasX10 + 16;

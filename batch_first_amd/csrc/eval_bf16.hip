@@ -80,6 +80,9 @@ static_assert((kPerC2Groups * C2_UNROLL) % CHUNK == 0 && (kPerC2Groups * C2_UNRO
               "the loop body is whole chunks and keeps the look-ahead phase");
 static_assert(kC2Tiles % C2_UNROLL == 0, "");
 static_assert(LA <= CHUNK && SHARE <= CHUNK, "");
+constexpr int WALK_CHUNKS = kStreamWalkGroups / CHUNK;   // chunks per board (the stream is walked as a ring)
+static_assert(kStreamWalkGroups % CHUNK == 0 && WALK_CHUNKS % SLOTS == 0 && kStreamWalkGroups % (LA + 1) == 0,
+              "every board starts in the same phase of the ring and of the register look-ahead");
 
 // Stage 1 finds the B operand of a tap in two steps: the shifted square's code from a byte
 // mailbox padded by 7 squares on every side (22 x 22, 15 = empty or off the board), then the
@@ -100,6 +103,8 @@ struct Lds {
     __attribute__((aligned(16))) unsigned char board[BPB][BOARD_BYTES];
     u32x4 onehot[16][2];                                 // stage 1: [code][lane half] -> 8 bf16 planes
     __attribute__((aligned(16))) float bias3[6][2][16];  // shifts of x4..x9 in accumulator order: [layer][lane half][register]
+    f32x4 hpart[WAVES][64];                              // stage 5: per-wave partial sums of the 8x8 layer
+    __attribute__((aligned(16))) unsigned char next_mailbox[WAVES][256];  // the wave's next board, prefetched by LDS-DMA
 };
 
 // Workgroup barrier for LDS hand-offs: every LDS access of this wave has completed; global
@@ -113,8 +118,12 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // slot refilled after the barrier is that of the chunk BEFORE the one just finished, whose reads
 // were issued more than CHUNK groups ago and have returned (LDS returns a wave's reads in order,
 // and every group waits for its own fragment, issued LA groups earlier, before its MFMAs).
+// EXTRA = 1 for the two barriers after the next board's mailbox prefetch (one more LDS-DMA, issued
+// right after a chunk's pieces): it is younger than the pieces those barriers need and may stay in
+// flight; the third barrier after it retires it (in order) with the pieces it waits for.
+template <int EXTRA>
 __device__ __forceinline__ void ring_barrier() {
-    constexpr int N = (SLOTS - 3) * SHARE;
+    constexpr int N = (SLOTS - 3) * SHARE + EXTRA;
     static_assert(SLOTS >= 3 && N < 64, "vmcnt is a 6-bit counter");
 #ifdef BF16_ABL_NOBAR
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -123,9 +132,16 @@ __device__ __forceinline__ void ring_barrier() {
 #endif
 }
 
+// The next board's mailbox is prefetched after the take of this group (stage 2, second hidden tile):
+// the take that issues the last piece of its chunk.
+constexpr int kPrefetchGroup = ((kGemmBase + kPerC2Groups + LA + CHUNK - 1) / CHUNK) * CHUNK + SHARE - 1 - LA;
+static_assert((kPrefetchGroup + LA) % CHUNK == SHARE - 1 && kPrefetchGroup >= kGemmBase &&
+              kPrefetchGroup + 3 * CHUNK < kStreamGroups, "");
+
 // Lockstep walk over the A-fragment stream through the LDS ring (see eval_f32.hip).
 struct WStream {
     const unsigned char* sbase;  // wave-uniform: this wave's share of the next chunk to fetch (global memory)
+    const unsigned char* sbase0; // ... of chunk 0: the walk wraps after WALK_CHUNKS chunks
     unsigned voff;               // lane * 16
     unsigned lds_share;          // LDS byte address of this wave's share of ring slot 0
     f32x4* ring;
@@ -150,6 +166,19 @@ struct WStream {
     __device__ __forceinline__ void set_m0(int slot_off) {
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(lds_share + (unsigned)slot_off * 16u) : "memory", "m0");
     }
+    // The scalar base of a chunk's pieces is computed where the chunk's refill starts, by two scalar adds
+    // the compiler cannot hoist: left to itself it keeps all 40 chunk bases of a board in SGPRs for the
+    // whole kernel (spilling others to VGPR lanes), and a base that sat unused from the first refill to
+    // the last one faulted on the GPU (the same instruction on a freshly computed base does not).
+    __device__ __forceinline__ void set_base(int chunk) {
+        const unsigned long long b0 = (unsigned long long)(uintptr_t)sbase0;
+        unsigned lo, hi;
+        asm volatile("s_add_u32 %0, %2, %4\n\ts_addc_u32 %1, %3, 0"
+                     : "=&s"(lo), "=s"(hi)
+                     : "s"((unsigned)b0), "s"((unsigned)(b0 >> 32)), "s"((unsigned)(chunk * CHUNK * 1024))
+                     : "scc");
+        sbase = reinterpret_cast<const unsigned char*>((uintptr_t)(((unsigned long long)hi << 32) | lo));
+    }
     __device__ __forceinline__ void fetch_piece(int i) {
         static_assert(SHARE <= 4, "immediate offsets of a global instruction reach 4095");
 #ifndef BF16_ABL_NODMA
@@ -158,17 +187,24 @@ struct WStream {
         if (i == 2) asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" ::"v"(voff), "s"(sbase) : "memory");
         if (i == 3) asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" ::"v"(voff), "s"(sbase) : "memory");
 #endif
-        if (i == SHARE - 1) sbase += CHUNK * 1024;
+    }
+    // The wave's next board (32 mailbox bytes) into lds.next_mailbox by LDS-DMA: lanes 0-7 carry it,
+    // the others repeat it.  Call right after the last piece of a chunk (M0 is set again at the next
+    // chunk barrier) and use ring_barrier<1> at the next two barriers.
+    __device__ __forceinline__ void prefetch_mailbox(const unsigned char* board_bytes, unsigned lds_dst, int lane) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2"
+                     ::"s"(lds_dst), "v"((unsigned)(lane & 7) * 4u), "s"(board_bytes) : "memory", "m0");
     }
     __device__ __forceinline__ void prime(const f32x4* stream, f32x4* ring_base, int lane, int wave) {
         typedef __attribute__((address_space(3))) f32x4* lds_ptr;
         ring = ring_base + lane;
         lds_share = (unsigned)(uintptr_t)(lds_ptr)(ring_base + wave * SHARE * 64);
-        sbase = reinterpret_cast<const unsigned char*>(stream + wave * SHARE * 64);
+        sbase0 = sbase = reinterpret_cast<const unsigned char*>(stream + wave * SHARE * 64);
         voff = (unsigned)lane * 16u;
 #pragma unroll
         for (int c = 0; c < SLOTS - 2; ++c) {
             set_m0(c * CHUNK * 64);
+            set_base(c);
 #pragma unroll
             for (int i = 0; i < SHARE; ++i) fetch_piece(i);
         }
@@ -176,28 +212,37 @@ struct WStream {
     }
     // After the barrier every wave's share of chunk k is in LDS and nobody reads chunk k-2 any
     // more, so its slot takes chunk k+SLOTS-2.
+    template <int EXTRA>
     __device__ __forceinline__ void next_chunk() {
         rd = (rd == (SLOTS - 1) * CHUNK * 64) ? 0 : rd + CHUNK * 64;
         fill = rd + (SLOTS - 2) * CHUNK * 64;
         if (fill >= SLOTS * CHUNK * 64) fill -= SLOTS * CHUNK * 64;
         __builtin_amdgcn_sched_barrier(0);
-        ring_barrier();
+        ring_barrier<EXTRA>();
         set_m0(fill);
         __builtin_amdgcn_sched_barrier(0);
     }
     __device__ __forceinline__ void start() {
-        next_chunk();
+        next_chunk<0>();
+        set_base(SLOTS - 2);
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
             if (i < SHARE) fetch_piece(i);
             pre[i] = ring[rd + i * 64];
         }
     }
+    // Every board starts with the ring in this state (WALK_CHUNKS is a multiple of SLOTS): telling the
+    // compiler so keeps the slot offsets compile-time constants inside the board loop.
+    __device__ __forceinline__ void board_start() { rd = 0; }
     // g: stream group index, a compile-time constant after unrolling; groups are taken in order.
     __device__ __forceinline__ bf16x8 take(int g) {
         const int nx = g + LA, i = nx % CHUNK;
-        if (i == 0) next_chunk();
+        // the mailbox prefetch follows the take of group kPrefetchGroup: its two next barriers allow for it
+        const bool extra = nx > kPrefetchGroup + LA && nx <= kPrefetchGroup + LA + 2 * CHUNK;
+        if (i == 0) { if (extra) next_chunk<1>(); else next_chunk<0>(); }
+        if (i == 0) set_base((nx / CHUNK + SLOTS - 2) % WALK_CHUNKS);
         if (i < SHARE) fetch_piece(i);
+
 #ifndef BF16_ABL_NOAREAD
         pre[nx % (LA + 1)] = ring[rd + i * 64];
 #endif
@@ -372,28 +417,27 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_bf16(const uint8_t* __restr
                                                            const float* __restrict__ bias,
                                                            const f32x4* __restrict__ headw,
                                                            float* __restrict__ scores, float* __restrict__ dbg) {
+    // Persistent workgroups: one per compute unit, each walks the board quads q = blockIdx.x,
+    // blockIdx.x + gridDim.x, ...  The weight ring never drains between boards (the stream is walked
+    // as a ring), the next board's mailbox arrives by LDS-DMA during stage 2, and the head kernels of
+    // the wave's squares stay in registers for the lifetime of the workgroup.
     constexpr bool DBG = MODE == 1;
     __shared__ __attribute__((aligned(16))) Lds lds;
     const int tid = threadIdx.x;
     const int lane = tid & 63, hl = lane >> 5, ln = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rank = ln >> 3, file = ln & 7;                 // tile 0; tile 1 is 4 ranks up
-    const unsigned board_raw = blockIdx.x * BPB + wave;
-    const unsigned board = board_raw < n_boards ? board_raw : n_boards - 1;  // padding boards repeat the last one
+    const unsigned n_quads = (n_boards + BPB - 1) / BPB;
+    typedef __attribute__((address_space(3))) unsigned char* lds_bytes;
 
 #ifdef BF_STAMPS
     long long stamps[16];
 #endif
-    BF_STAMP(0);
-#ifdef BF_STAMPS
-    if (lane == 0) stamps[7] = __builtin_amdgcn_s_memrealtime();  // constant 100 MHz clock, common to the chip
-#endif
     WStream ws;
     ws.prime(wstream, &lds.wring[0][0][0], lane, wave);
 
-    // ---- byte mailbox (15 everywhere, then the board's codes) and the one-hot table ----------
+    // ---- once per workgroup: the one-hot table, the 3x3 layers' shifts, the head kernels ----------
     unsigned char* region = lds.board[wave];
-    for (int i = lane; i < MB_WORDS; i += 64) reinterpret_cast<unsigned*>(region)[i] = 0x0F0F0F0Fu;
     if (tid < 32) {
         const unsigned c = tid >> 1, hh = tid & 1, j = c & 7u;
         const unsigned one = (c != 15u && (c >> 3) == hh) ? (0x3F80u << ((j & 1u) * 16u)) : 0u;
@@ -406,14 +450,54 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_bf16(const uint8_t* __restr
     }
     for (int i = tid; i < 6 * 32; i += THREADS)
         lds.bias3[i >> 5][(i >> 4) & 1][i & 15] = bias[kBiasX4 + 32 * (i >> 5) + rowmap(i & 15, (i >> 4) & 1)];
+    constexpr int SQW = 64 / WAVES;  // squares (k-steps of the head) per wave
+    u32x4 ha[SQW];
+    if (MODE != 2) {
+        const f32x4* hwp = headw + (size_t)wave * SQW * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < SQW; ++i) ha[i] = __builtin_bit_cast(u32x4, hwp[i * 64]);
+    }
+    // shift and logit weight of this thread's channel of the 8x8 layer (the reducing threads, tid < 16 * BPB):
+    // loaded once, because a compiler-tracked global load inside the board loop would be waited for with
+    // vmcnt(0), i.e. behind every LDS-DMA piece in flight
+    const float head_shift = MODE != 2 ? bias[kBiasX10 + (tid & 15)] : 0.0f;
+    const float head_logit = MODE != 2 ? bias[kLogitW + (tid & 15)] : 0.0f;
+    {   // the first board's mailbox directly (every later one is prefetched)
+        const unsigned b0 = blockIdx.x * BPB + wave;
+        const unsigned bc = b0 < n_boards ? b0 : n_boards - 1;
+        if (lane < 8)
+            reinterpret_cast<unsigned*>(lds.next_mailbox[wave])[lane] =
+                reinterpret_cast<const unsigned*>(mailbox + (size_t)bc * kMailboxBytes)[lane];
+    }
+    lds_order();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the table writes have reached LDS ...
+    ws.start();  // ... before its barrier lets stage 1 of any wave read them
+
+#pragma unroll 1
+    for (unsigned quad = blockIdx.x; quad < n_quads; quad += gridDim.x) {
+    const unsigned board_raw = quad * BPB + wave;
+    const unsigned board = board_raw < n_boards ? board_raw : n_boards - 1;  // padding boards repeat the last one
+    unsigned next_raw = (quad + gridDim.x) * BPB + wave;                      // prefetched in stage 2
+    const unsigned next_board = __builtin_amdgcn_readfirstlane(next_raw < n_boards ? next_raw : n_boards - 1);
+    ws.board_start();
+    BF_STAMP(0);
+#ifdef BF_STAMPS
+    if (lane == 0) stamps[7] = __builtin_amdgcn_s_memrealtime();  // constant 100 MHz clock, common to the chip
+#endif
+
+    // ---- byte mailbox: 15 everywhere, then the board's codes ---------------------------------
+    for (int i = lane; i < MB_WORDS; i += 64) reinterpret_cast<unsigned*>(region)[i] = 0x0F0F0F0Fu;
     lds_order();
     {
+#ifndef BF16_NO_PREFETCH
+        const unsigned v = lds.next_mailbox[wave][lane >> 1];
+#else
         const unsigned v = mailbox[(size_t)board * kMailboxBytes + (lane >> 1)];
+#endif
         const unsigned c = (lane & 1) ? (v >> 4) : (v & 15u);
         region[((lane >> 3) + 7) * MB_W + (lane & 7) + 7] = (unsigned char)c;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the table writes have reached LDS ...
-    ws.start();  // ... before its barrier lets stage 1 of any wave read them
+    lds_order();
 
     float* dbg_board = DBG ? dbg + (size_t)board * kDebugFloatsPerBoard : nullptr;
     BF_STAMP(1);
@@ -454,6 +538,13 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_bf16(const uint8_t* __restr
 #pragma unroll
             for (int s = 0; s < kGemm1Groups; ++s) {  // phase A: 236->512, tile 0
                 f[s] = ws.take(g0 + s);
+#ifndef BF16_NO_PREFETCH
+                if (g0 + s == kPrefetchGroup)
+#else
+                if (false)
+#endif
+                    ws.prefetch_mailbox(mailbox + (size_t)next_board * kMailboxBytes,
+                                        (unsigned)(uintptr_t)(lds_bytes)lds.next_mailbox[wave], lane);
                 const u32x4 b = u32x4{P[0][4 * s], P[0][4 * s + 1], P[0][4 * s + 2], P[0][4 * s + 3]};
                 acc2[0] = BF_MFMA16(f[s], __builtin_bit_cast(bf16x8, b), s == 0 ? zero16() : acc2[0]);
             }
@@ -538,12 +629,6 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_bf16(const uint8_t* __restr
         return *reinterpret_cast<const u32x4*>(region + (c & 1) * PLANE_BYTES + raddr[tap / 3][s] + T * TILE1 + (tap % 3) * POS_BYTES);
     };
     constexpr int D = 4, NSLOTS = 9 * 36;
-    // Head kernels of this wave's squares (stage 5), fetched during the last but one layer so that their
-    // L2 latency is not exposed after the last MFMA: 16 plain loads right after a ring barrier (the next
-    // barrier's counted vmcnt then covers them too, 16 groups later).
-    constexpr int SQW = 64 / WAVES;  // squares (k-steps of the head) per wave
-    u32x4 ha[SQW];
-    const f32x4* hwp = headw + (size_t)wave * SQW * 64 + lane;
     f32x16 A[2][2];   // [set][tile]: chunks 0..3 accumulate in set 0, layer c >= 4 in set (c & 1) ^ 1
     f32x16 bs;        // shift of the layer about to start
     u32x4 bq[D];
@@ -563,10 +648,6 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_bf16(const uint8_t* __restr
     for (int n = 0; n < NSLOTS; ++n) {
         const int c = slot_c(n), r = n % 36, T = slot_T(n), idx = slot_idx(n);
         if (n == 4 * 36) BF_STAMP(4);
-        if (MODE != 2 && n == 7 * 36 + 12) {
-#pragma unroll
-            for (int i = 0; i < SQW; ++i) ha[i] = __builtin_bit_cast(u32x4, hwp[i * 64]);
-        }
         const bool joint = c < 3;
         const int o = c <= 3 ? 0 : ((c & 1) ^ 1);
         bf16x8 w;
@@ -594,8 +675,12 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_bf16(const uint8_t* __restr
     f32x16 (&acc)[2] = A[1];  // x9 before its ReLU
 
     BF_STAMP(5);
+    // The walk's padding groups: they bring the ring and the look-ahead back to their start phase,
+    // with the next board's first fragments already on their way into registers.
+#pragma unroll
+    for (int g = kStreamGroups; g < kStreamWalkGroups; ++g) (void)ws.take(g);
+
     // ---- stage 5: 8x8 valid conv (2048 -> 16) across the workgroup's boards, ReLU, logit ------
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring's look-ahead DMA must not outlive the workgroup
     if (MODE == 2) {
         if (board_raw < n_boards) {
             float* out = scores + (size_t)board * 2048;
@@ -604,8 +689,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_bf16(const uint8_t* __restr
 #pragma unroll
                 for (int t = 0; t < 16; ++t) out[rowmap(t, hl) * 64 + 32 * T + ln] = fmaxf(acc[T][t], 0.0f);
         }
-        return;
-    }
+    } else {
     lds_order();
 #pragma unroll
     for (int p = 0; p < 8; ++p) write_piece(1, p >> 2, p & 3, acc[p >> 2]);   // x9 -> plane 1
@@ -614,43 +698,62 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_bf16(const uint8_t* __restr
         dump_tile(dbg_board + 64 * (236 + 128 + 32 * 5), hl, 32 + ln, acc[1]);
     }
     const int col = lane & 15, kc = lane >> 4;
-    __syncthreads();
+    lds_barrier();   // every wave's x9 is in its plane 1 (LDS only: the ring's DMA stays in flight)
     {
+        // out[board][co] = sum over (square, ci) of x9[board][square][ci] * W[square][ci][co]: the two
+        // operands of v_mfma_f32_16x16x32_bf16 have the same lane layout, so the activations go first
+        // (rows = boards) and the kernels second, where they can stay in the registers they were loaded
+        // into; all of the wave's activation reads are issued before the first MFMA.
         const unsigned char* xb = lds.board[col < BPB ? col : 0] + PLANE_BYTES;
-        f32x4 hacc = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x4 hb[SQW];
 #pragma unroll
         for (int i = 0; i < SQW; ++i) {
             const int sqk = wave * SQW + i;
             const int Rk = (sqk >> 3) + 1;
-            const u32x4 b = *reinterpret_cast<const u32x4*>(xb + (Rk * XP_W + (sqk & 7) + 1) * POS_BYTES + (((kc + Rk) & 3) << 4));
-            hacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ha[i]), __builtin_bit_cast(bf16x8, b),
-                                                           hacc, 0, 0, 0);
+            hb[i] = *reinterpret_cast<const u32x4*>(xb + (Rk * XP_W + (sqk & 7) + 1) * POS_BYTES + (((kc + Rk) & 3) << 4));
         }
-        // partial sums go to plane 0 of this wave's board (nobody else reads it)
-        reinterpret_cast<f32x4*>(region)[lane] = hacc;
+        __builtin_amdgcn_sched_barrier(0);
+        // Inline asm so that the kernels are read from the AGPRs they live in (the builtin copies each to
+        // VGPRs first: 4 x 8 cycles of issue per 16-cycle MFMA).  One accumulation chain on one register
+        // (no wait states needed between its links); the s_nop after the last link covers the
+        // MFMA-result-to-LDS-store hazard, which the compiler does not see through inline asm.
+        f32x4 hacc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < SQW; ++i)
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(hacc) : "v"(hb[i]), "a"(ha[i]));
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(hacc));
+        lds.hpart[wave][lane] = hacc;
     }
-    __syncthreads();
+    // After this barrier nobody reads a plane of this board any more (the next board may overwrite
+    // them), and hpart is complete; it is rewritten one board later, behind the next barrier of
+    // this kind, which the reducing wave reaches only after its reads.
+    lds_barrier();
     if (tid < 16 * BPB) {
         const int b = tid >> 4, co = tid & 15;
-        // D[row = co][col = b] sits in lane b + 16*(co>>2), register co&3
+        // D[row = b][col = co] sits in lane co + 16*(b>>2), register b&3
         float s = 0.0f;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w)
-            s += reinterpret_cast<const float*>(lds.board[w])[(b + 16 * (co >> 2)) * 4 + (co & 3)];
-        const float y = fmaxf(s + bias[kBiasX10 + co], 0.0f);
-        const unsigned out_raw = blockIdx.x * BPB + b;
+            s += reinterpret_cast<const float*>(lds.hpart[w])[(co + 16 * (b >> 2)) * 4 + (b & 3)];
+        const float y = fmaxf(s + head_shift, 0.0f);
+        const unsigned out_raw = quad * BPB + b;
         if (DBG && out_raw < n_boards) dbg[(size_t)out_raw * kDebugFloatsPerBoard + 64 * (236 + 128 + 32 * 6) + co] = y;
-        float v = y * bias[kLogitW + co];  // logit_layer: no bias, no batch-norm (evaluation_ann.py:35-44)
+        float v = y * head_logit;  // logit_layer: no bias, no batch-norm (evaluation_ann.py:35-44)
         v += __shfl_xor(v, 1);
         v += __shfl_xor(v, 2);
         v += __shfl_xor(v, 4);
         v += __shfl_xor(v, 8);
         if (co == 0 && out_raw < n_boards) scores[out_raw] = v;
     }
-#ifdef BF_STAMPS
+    }
     BF_STAMP(6);
+#ifdef BF_STAMPS
     if (lane == 0) stamps[14] = __builtin_amdgcn_s_memrealtime();
-    if (!DBG && dbg && lane == 0) {
+#endif
+    }  // board loop
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring's look-ahead DMA must not outlive the workgroup
+#ifdef BF_STAMPS
+    if (!DBG && dbg && lane == 0) {   // stamps of the workgroup's last board
         long long* out = reinterpret_cast<long long*>(dbg) + ((size_t)blockIdx.x * WAVES + wave) * 16;
         for (int i = 0; i < 15; ++i) out[i] = stamps[i];
     }
@@ -661,6 +764,24 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_bf16(const uint8_t* __restr
 
 hipError_t launch(const uint8_t* d_mailbox, size_t n, const unsigned char* d_image, float* d_scores, float* d_debug,
                   hipStream_t stream);
+
+// One persistent workgroup per compute unit of the current device (fewer for small batches).
+hipError_t grid_blocks(size_t n, unsigned* blocks) {
+    static int cus[64] = {0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    int count = (dev >= 0 && dev < 64) ? cus[dev] : 0;
+    if (count == 0) {
+        e = hipDeviceGetAttribute(&count, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return e;
+        if (count <= 0) count = 256;
+        if (dev >= 0 && dev < 64) cus[dev] = count;
+    }
+    const size_t quads = (n + BPB - 1) / BPB;
+    *blocks = (unsigned)(quads < (size_t)count ? quads : (size_t)count);
+    return hipSuccess;
+}
 
 }  // namespace b16
 
@@ -673,7 +794,10 @@ hipError_t launch_policy_features_bf16(const uint8_t* d_mailbox, size_t n, const
                                        hipStream_t stream) {
     using namespace b16;
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_eval_bf16<2>, dim3((unsigned)((n + BPB - 1) / BPB)), dim3(THREADS), 0, stream, d_mailbox,
+    unsigned blocks = 0;
+    hipError_t e = grid_blocks(n, &blocks);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_eval_bf16<2>, dim3(blocks), dim3(THREADS), 0, stream, d_mailbox,
                        (unsigned)n, reinterpret_cast<const f32x4*>(d_image + b16::kOffStream),
                        reinterpret_cast<const float*>(d_image + b16::kOffBias),
                        reinterpret_cast<const f32x4*>(d_image + b16::kOffHead), d_x9, nullptr);
@@ -686,7 +810,9 @@ hipError_t b16::launch(const uint8_t* d_mailbox, size_t n, const unsigned char* 
     const f32x4* ws = reinterpret_cast<const f32x4*>(d_image + kOffStream);
     const float* bias = reinterpret_cast<const float*>(d_image + kOffBias);
     const f32x4* head = reinterpret_cast<const f32x4*>(d_image + kOffHead);
-    const unsigned blocks = (unsigned)((n + BPB - 1) / BPB);
+    unsigned blocks = 0;
+    hipError_t e = grid_blocks(n, &blocks);
+    if (e != hipSuccess) return e;
 #ifdef BF_STAMPS
     if (false)
 #else

@@ -14,7 +14,7 @@ INPUT_CONVS = [(3, 1, 1, 64, 0, 2), (3, 2, 2, 32, 64, 1), (3, 3, 3, 20, 96, 1), 
                (2, 4, 2, 24, 212, 1)]
 X1_REG_BASE = [0, 32, 48, 58, 68, 78, 88, 96, 108]
 X1_REG_COUNT = [32, 16, 10, 10, 10, 10, 8, 12, 12]
-STREAM_GROUPS, STREAM_PAD = 626, 62
+STREAM_GROUPS, STREAM_PAD = 626, 14
 B_X3, B_X4, B_X10, B_LOGIT, BIAS_FLOATS = 0, 128, 320, 336, 352
 OFF_BIAS = (STREAM_GROUPS + STREAM_PAD) * 1024
 OFF_HEAD = OFF_BIAS + ((BIAS_FLOATS * 4 + 255) & ~255)
