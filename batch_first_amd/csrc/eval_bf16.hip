@@ -13,7 +13,7 @@
 // MFMA per fragment read): the kernel was bound by LDS traffic -- the fragment reads plus the
 // LDS-DMA writes that fill the ring -- not by the matrix pipe; removing either in an ablation
 // build took 0.6 ms off 2.1 ms.  A whole board per wave halves both.  The price is registers
-// (x1 and the 128-channel accumulators of both tiles live in them: ~330), so one wave per SIMD.
+// (x1 and the 128-channel accumulators of both tiles live in them: ~400), so one wave per SIMD.
 // Layers run transposed, out^T[channel][square] = W^T[channel][k] * in^T[k][square], so that a
 // finished accumulator tile, converted to bf16 in place, is the B operand of the next 1x1 layer
 // (k order permuted on the host to match the accumulator's row map).
@@ -29,8 +29,15 @@
 //   stage 5  8x8 valid conv across the boards of the workgroup: out[co][board] on
 //            v_mfma_f32_16x16x32_bf16, one k-step per square, squares split over the waves, fixed-
 //            order reduction of the per-wave partial sums; ReLU; logit.
-// Weights stream through a lockstep LDS ring as in the fp32 kernel (LDS-DMA into a 3-slot ring,
-// one barrier per chunk), with one 1-KiB group per fragment and a 3-group register look-ahead.
+// Weights stream through a lockstep LDS ring as in the fp32 kernel (LDS-DMA into a 4-slot ring,
+// one barrier per 16-group chunk), with one 1-KiB group per fragment and a 7-group register
+// look-ahead.  Workgroups are persistent (one per compute unit): the stream is walked as a ring,
+// board after board, the next board's mailbox is prefetched by LDS-DMA, the head kernels stay in
+// registers.  With one wave per SIMD the kernel is bound by instructions issued per MFMA gap
+// (tools/issue_rate.hip: scalar ALU, v_accvgpr_read and dependent VALU instructions cost 8 cycles
+// of issue each), hence: MFMA results in VGPRs (build flag -amdgpu-mfma-vgpr-form), one
+// instruction per LDS-DMA piece, every stage a flat list of MFMA slots with the LDS reads, packs
+// and LDS writes of its neighbours placed in the gaps.  DESIGN.md section 3.2 has the measurements.
 // Results are bit-reproducible and independent of a board's position in the batch.
 #include <hip/hip_runtime.h>
 
