@@ -159,3 +159,18 @@ def test_bf16_batch_65536_properties(ctx16, golden, model_scores):
     assert np.all(s.view(np.uint32) == s.view(np.uint32)[0:1])
     e, _ = _rel(s[63], model_scores)
     assert e.max() <= MODEL_TOL
+
+
+def test_bf16_ragged_batches_on_persistent_workgroups(ctx16, golden):
+    """The bf16 kernel runs one persistent workgroup per compute unit over the board quads: batches that
+    give the workgroups unequal numbers of quads, a partial last quad, or fewer quads than units must
+    score every board exactly as the 1024-board batch does (size-independent property; the oracle
+    comparison of those 1024 scores is test_bf16_scores_match_model_and_fp32_oracle)."""
+    import torch
+    base = torch.ops.batchfirst.eval_structs(ctx16.handle, torch.from_numpy(golden["records"].copy()).cuda()).cpu().numpy()
+    for n in (1, 3, 5, 1023, 1025, 2051, 4099, 9001):
+        idx = (np.arange(n) * 7 + 3) % 1024
+        recs = torch.from_numpy(golden["records"][idx].copy()).cuda()
+        got = torch.ops.batchfirst.eval_structs(ctx16.handle, recs).cpu().numpy()
+        assert got.shape == (n,)
+        assert np.array_equal(got.view(np.uint32), base[idx].view(np.uint32)), n
