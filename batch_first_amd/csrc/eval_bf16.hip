@@ -174,9 +174,11 @@ struct WStream {
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(lds_share + (unsigned)slot_off * 16u) : "memory", "m0");
     }
     // The scalar base of a chunk's pieces is computed where the chunk's refill starts, by two scalar adds
-    // the compiler cannot hoist: left to itself it keeps all 40 chunk bases of a board in SGPRs for the
-    // whole kernel (spilling others to VGPR lanes), and a base that sat unused from the first refill to
-    // the last one faulted on the GPU (the same instruction on a freshly computed base does not).
+    // the compiler cannot hoist.  Left to itself it keeps all 40 chunk bases of a board in SGPRs for the
+    // whole kernel and spills ~30 other SGPRs to VGPR lanes; builds of that form faulted on the GPU
+    // (memory aperture violation) whenever one of those bases stayed live from the first refill to the
+    // walk's last one, with every address in the ISA correct as far as it could be read -- cause not
+    // established; this form has no such long-lived registers and at most one spilled pair.
     __device__ __forceinline__ void set_base(int chunk) {
         const unsigned long long b0 = (unsigned long long)(uintptr_t)sbase0;
         unsigned lo, hi;
