@@ -21,7 +21,7 @@
 //             (all-zero taps, shift 1.0): k-slots whose B element is exactly 1.0, through which
 //             the 1x1 236->512 layer receives its shift, again as three exact bf16 terms.
 //   1x1 pair  per 32-channel tile of the hidden layer: 15 groups (236->512), 8 groups
-//             (512->128: k-step s = 0,1 x output tile 0..3), 1 padding group.
+//             (512->128: k-step s = 0,1 x output tile 0..3), 1 padding group; stream order kGemmOrder.
 //   3x3       per (32-channel input chunk, tap, k-step s): conv4 = 4 x 9 x 2, conv5..9 = 5 x 9 x 2.
 //   head      8x8 valid conv as out[co][board] = sum over (sq, ci): one v_mfma_f32_16x16x32_bf16
 //             per square, A[row = co][k = ci] (separate image, not part of the stream).
@@ -50,6 +50,33 @@ constexpr int kGemm1Groups = 15;
 constexpr int kGemm2Groups = 8;
 constexpr int kPerC2Groups = 24;        // 15 + 8 + 1 padding group: two tiles = whole chunks
 constexpr int kC2Tiles = 16;
+// Order of the 16 x 24 groups of the 1x1 pair in the stream = the order the kernel takes them in.  The
+// pair is software-pipelined across the hidden layer's 32-channel tiles: while tile u+1's 15 groups of
+// the 236->512 layer multiply (both board tiles share each fragment as it arrives), tile u's result is
+// packed and its 8 groups of the 512->128 layer are interleaved, so no phase of the pair reads a
+// fragment per MFMA or waits for a pack.  kind 0: 236->512 (idx = k-step 0..14); kind 1: 512->128
+// (idx = 4 * k-step + output tile, 0..7); kind 2: padding group (all at the end of the section).
+struct GemmOrder {
+    signed char kind[16 * 24], tile[16 * 24], idx[16 * 24];
+};
+constexpr int kGemmStepSeq[23] = {0, 1, 2, 3, 100, 4, 101, 5, 102, 6, 103, 7, 8, 104, 9, 105, 10, 106, 11, 107, 12, 13, 14};
+constexpr GemmOrder make_gemm_order() {
+    GemmOrder o{};
+    int p = 0;
+    for (int s = 0; s < 15; ++s, ++p) { o.kind[p] = 0; o.tile[p] = 0; o.idx[p] = (signed char)s; }
+    for (int u = 0; u < 15; ++u)
+        for (int j = 0; j < 23; ++j, ++p) {
+            const int e = kGemmStepSeq[j];
+            if (e < 100) { o.kind[p] = 0; o.tile[p] = (signed char)(u + 1); o.idx[p] = (signed char)e; }
+            else { o.kind[p] = 1; o.tile[p] = (signed char)u; o.idx[p] = (signed char)(e - 100); }
+        }
+    for (int i = 0; i < 8; ++i, ++p) { o.kind[p] = 1; o.tile[p] = 15; o.idx[p] = (signed char)i; }
+    for (; p < 16 * 24; ++p) { o.kind[p] = 2; o.tile[p] = 0; o.idx[p] = 0; }
+    return o;
+}
+constexpr GemmOrder kGemmOrder = make_gemm_order();
+static_assert(kC2Tiles == 16 && kPerC2Groups == 24 && kGemm1Groups == 15 && kGemm2Groups == 8, "kGemmOrder is written for these");
+
 constexpr int kConv4Groups = 4 * 9 * 2;   // 72
 constexpr int kConv59Groups = 5 * 9 * 2;  // 90
 constexpr int kGemmBase = kInputGroups;

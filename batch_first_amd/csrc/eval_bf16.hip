@@ -533,61 +533,62 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_bf16(const uint8_t* __restr
             acc3[1][c3][t] = acc3[0][c3][t];
         }
 
-#pragma unroll 1
-    for (int it = 0; it < kC2Tiles / C2_UNROLL; ++it) {
+    // Software pipeline across the hidden layer's 32-channel tiles, in the stream order kGemmOrder: while
+    // tile u+1's 15 groups of the 236->512 layer multiply (both board tiles share each fragment as it
+    // arrives: one LDS read per two MFMAs), tile u's accumulators are packed (ReLU + bf16, two
+    // instructions per dword, at most three dwords per group) and its 8 groups of the 512->128 layer
+    // are interleaved.  No fragment is held in registers, no phase reads a fragment per MFMA, and the
+    // only pack the matrix pipe waits for is that of the last tile.
+    {
+        f32x16 acc2[2][2];   // [buffer = hidden tile & 1][board tile]
+        unsigned H[2][8];    // packed hidden tile: [board tile][dword], B operands of its 512->128 groups
+        auto pack_piece = [&](int buf, int k) {   // k = 0..15: dwords 0-3 of tile 0, of tile 1, then dwords 4-7
+            const int T = (k >> 2) & 1, j = (k & 3) + 4 * (k >> 3);
+            H[T][j] = pack_relu(acc2[buf][T][2 * j], acc2[buf][T][2 * j + 1]);
+        };
 #pragma unroll
-        for (int u = 0; u < C2_UNROLL; ++u) {
-            const int g0 = kGemmBase + u * kPerC2Groups;
-            // The two tiles run half a phase apart: tile 0 uses each fragment as it arrives and
-            // keeps it in registers for tile 1, so that one tile's ReLU + pack (which has to wait
-            // for its last MFMA) rides in the MFMA gaps of the other tile instead of idling the pipe.
-            f32x16 acc2[2];
-            bf16x8 f[kGemm1Groups];
-            if (it * C2_UNROLL + u == 2) BF_STAMP(8);
-#pragma unroll
-            for (int s = 0; s < kGemm1Groups; ++s) {  // phase A: 236->512, tile 0
-                f[s] = ws.take(g0 + s);
+        for (int p = 0; p < kC2Tiles * kPerC2Groups; ++p) {
+            const int g = kGemmBase + p;
+            const int kind = kGemmOrder.kind[p], tile = kGemmOrder.tile[p], idx = kGemmOrder.idx[p];
+            if (p == 15 + 23) BF_STAMP(8);
+            if (p == 15 + 2 * 23) BF_STAMP(9);
+            const bf16x8 w = ws.take(g);
 #ifndef BF16_NO_PREFETCH
-                if (g0 + s == kPrefetchGroup)
-#else
-                if (false)
+            if (g == kPrefetchGroup)
+                ws.prefetch_mailbox(mailbox + (size_t)next_board * kMailboxBytes,
+                                    (unsigned)(uintptr_t)(lds_bytes)lds.next_mailbox[wave], lane);
 #endif
-                    ws.prefetch_mailbox(mailbox + (size_t)next_board * kMailboxBytes,
-                                        (unsigned)(uintptr_t)(lds_bytes)lds.next_mailbox[wave], lane);
-                const u32x4 b = u32x4{P[0][4 * s], P[0][4 * s + 1], P[0][4 * s + 2], P[0][4 * s + 3]};
-                acc2[0] = BF_MFMA16(f[s], __builtin_bit_cast(bf16x8, b), s == 0 ? zero16() : acc2[0]);
-            }
-            if (it * C2_UNROLL + u == 2) BF_STAMP(9);
-            unsigned H[2][8];
+            if (kind == 0) {
 #pragma unroll
-            for (int s = 0; s < kGemm1Groups; ++s) {  // phase B: 236->512, tile 1 | pack tile 0
-                const u32x4 b = u32x4{P[1][4 * s], P[1][4 * s + 1], P[1][4 * s + 2], P[1][4 * s + 3]};
-                acc2[1] = BF_MFMA16(f[s], __builtin_bit_cast(bf16x8, b), s == 0 ? zero16() : acc2[1]);
-                if (s >= 3 && s < 11) H[0][s - 3] = pack_relu(acc2[0][2 * (s - 3)], acc2[0][2 * (s - 3) + 1]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (it * C2_UNROLL + u == 2) BF_STAMP(10);
-            bf16x8 h[kGemm2Groups];
+                for (int T = 0; T < 2; ++T) {
+                    const u32x4 b = u32x4{P[T][4 * idx], P[T][4 * idx + 1], P[T][4 * idx + 2], P[T][4 * idx + 3]};
+                    acc2[tile & 1][T] = BF_MFMA16(w, __builtin_bit_cast(bf16x8, b), idx == 0 ? zero16() : acc2[tile & 1][T]);
+                }
+            } else if (kind == 1) {
+                const int sk = idx >> 2, c3 = idx & 3;
 #pragma unroll
-            for (int i = 0; i < kGemm2Groups; ++i) {  // phase C: 512->128, tile 0 | pack tile 1
-                const int s = i >> 2, c3 = i & 3;
-                h[i] = ws.take(g0 + kGemm1Groups + i);
-                const u32x4 b = u32x4{H[0][4 * s], H[0][4 * s + 1], H[0][4 * s + 2], H[0][4 * s + 3]};
-                acc3[0][c3] = BF_MFMA16(h[i], __builtin_bit_cast(bf16x8, b), acc3[0][c3]);
-                if (i >= 1) H[1][i - 1] = pack_relu(acc2[1][2 * (i - 1)], acc2[1][2 * (i - 1) + 1]);
-                if (i == 7) H[1][7] = pack_relu(acc2[1][14], acc2[1][15]);
+                for (int T = 0; T < 2; ++T) {
+                    const u32x4 b = u32x4{H[T][4 * sk], H[T][4 * sk + 1], H[T][4 * sk + 2], H[T][4 * sk + 3]};
+                    acc3[T][c3] = BF_MFMA16(w, __builtin_bit_cast(bf16x8, b), acc3[T][c3]);
+                }
             }
-            (void)ws.take(g0 + kPerC2Groups - 1);  // padding group
-            if (it * C2_UNROLL + u == 2) BF_STAMP(11);
+            // packs of the tile whose 236->512 groups ended with the previous step
+            if (p >= 15 && p < 15 + 15 * 23) {
+                const int u = (p - 15) / 23, j = (p - 15) % 23;
+                const int first = j == 0 ? 0 : j == 1 ? 0 : j == 2 ? 3 : j == 3 ? 6 : 8 + (j - 4);
+                const int count = j == 0 ? 0 : j <= 2 ? 3 : j == 3 ? 2 : j <= 11 ? 1 : 0;
 #pragma unroll
-            for (int i = 0; i < kGemm2Groups; ++i) {  // phase D: 512->128, tile 1
-                const int s = i >> 2, c3 = i & 3;
-                const u32x4 b = u32x4{H[1][4 * s], H[1][4 * s + 1], H[1][4 * s + 2], H[1][4 * s + 3]};
-                acc3[1][c3] = BF_MFMA16(h[i], __builtin_bit_cast(bf16x8, b), acc3[1][c3]);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int k = 0; k < count; ++k) pack_piece(u & 1, first + k);
             }
-            if (it * C2_UNROLL + u == 2) BF_STAMP(12);
-            if (it * C2_UNROLL + u == 3) BF_STAMP(13);
+            if (p == 15 + 15 * 23 - 1) {   // the last tile: its first half before its own 512->128 groups start
+#pragma unroll
+                for (int k = 0; k < 8; ++k) pack_piece(15 & 1, k);
+            }
+            if (p >= 15 + 15 * 23 && p < 15 + 15 * 23 + 4) {
+                pack_piece(15 & 1, 8 + 2 * (p - 15 - 15 * 23));
+                pack_piece(15 & 1, 9 + 2 * (p - 15 - 15 * 23));
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     if (DBG) {

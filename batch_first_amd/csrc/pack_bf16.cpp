@@ -141,36 +141,36 @@ void pack(const float* blob, unsigned char* image, bool policy) {
             }
         return -1;
     };
-    for (int c2 = 0; c2 < kC2Tiles; ++c2) {
-        for (int s = 0; s < kGemm1Groups; ++s) {
-            for (int lane = 0; lane < 64; ++lane) {
-                const int h = lane >> 5, co = c2 * 32 + (lane & 31);
-                uint16_t parts[3];
-                split3(shift[1][co], parts);
-                for (int j = 0; j < 8; ++j) {
-                    const int reg = 8 * s + j;
-                    const int ci = x1_channel(reg, h);
-                    uint16_t v = 0;
-                    if (ci >= 0) v = to_bf16(c.tower_w[0][(size_t)ci * kC2 + co] * inv[1][co]);
-                    else if (reg == kOnesRegA) v = parts[h];            // hi on half 0, mid on half 1
-                    else if (reg == kOnesRegB && h == 0) v = parts[2];  // lo
-                    slot(lane, j) = v;
-                }
+    auto write_g1 = [&](int c2, int s) {
+        for (int lane = 0; lane < 64; ++lane) {
+            const int h = lane >> 5, co = c2 * 32 + (lane & 31);
+            uint16_t parts[3];
+            split3(shift[1][co], parts);
+            for (int j = 0; j < 8; ++j) {
+                const int reg = 8 * s + j;
+                const int ci = x1_channel(reg, h);
+                uint16_t v = 0;
+                if (ci >= 0) v = to_bf16(c.tower_w[0][(size_t)ci * kC2 + co] * inv[1][co]);
+                else if (reg == kOnesRegA) v = parts[h];            // hi on half 0, mid on half 1
+                else if (reg == kOnesRegB && h == 0) v = parts[2];  // lo
+                slot(lane, j) = v;
             }
-            ++group;
         }
-        for (int s = 0; s < 2; ++s)
-            for (int c3 = 0; c3 < 4; ++c3) {
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int h = lane >> 5, co = c3 * 32 + (lane & 31);
-                    for (int j = 0; j < 8; ++j) {
-                        const int ci = c2 * 32 + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
-                        slot(lane, j) = to_bf16(c.tower_w[1][(size_t)ci * kC3 + co] * inv[2][co]);
-                    }
-                }
-                ++group;
+    };
+    auto write_g2 = [&](int c2, int i) {
+        const int s = i >> 2, c3 = i & 3;
+        for (int lane = 0; lane < 64; ++lane) {
+            const int h = lane >> 5, co = c3 * 32 + (lane & 31);
+            for (int j = 0; j < 8; ++j) {
+                const int ci = c2 * 32 + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
+                slot(lane, j) = to_bf16(c.tower_w[1][(size_t)ci * kC3 + co] * inv[2][co]);
             }
-        ++group;  // padding group
+        }
+    };
+    for (int p = 0; p < kC2Tiles * kPerC2Groups; ++p) {   // in the order the kernel takes them (kGemmOrder)
+        if (kGemmOrder.kind[p] == 0) write_g1(kGemmOrder.tile[p], kGemmOrder.idx[p]);
+        else if (kGemmOrder.kind[p] == 1) write_g2(kGemmOrder.tile[p], kGemmOrder.idx[p]);
+        ++group;   // kind 2: padding group, zeros
     }
     // 3. 3x3 layers: natural channel order, k = 16s + 8h + j within a 32-channel chunk
     auto conv3 = [&](const float* w, int cin, int chunk, const std::vector<float>& scale) {

@@ -20,6 +20,21 @@ OFF_BIAS = (STREAM_GROUPS + STREAM_PAD) * 1024
 OFF_HEAD = OFF_BIAS + ((BIAS_FLOATS * 4 + 255) & ~255)
 
 
+def _gemm_order():
+    """bf_layout_bf16.h:kGemmOrder -- (kind, hidden tile, index) of the 16 x 24 groups of the 1x1 pair."""
+    seq = [0, 1, 2, 3, 100, 4, 101, 5, 102, 6, 103, 7, 8, 104, 9, 105, 10, 106, 11, 107, 12, 13, 14]
+    order = [(0, 0, s) for s in range(15)]
+    for u in range(15):
+        order += [(0, u + 1, e) if e < 100 else (1, u, e - 100) for e in seq]
+    order += [(1, 15, i) for i in range(8)]
+    order += [(2, 0, 0)] * (16 * 24 - len(order))
+    assert len(order) == 16 * 24
+    return order
+
+
+GEMM_ORDER = _gemm_order()
+
+
 def bf16r(x):
     """float -> nearest bf16 (ties to even) as float64."""
     u = np.ascontiguousarray(x, np.float32).view(np.uint32)
@@ -93,15 +108,18 @@ def eval_boards(image, mailboxes):
             for c3 in range(4):
                 for t in range(16):
                     acc3[c3, t] = bias[B_X3 + 32 * c3 + rowmap(t, HL)]
-            for c2 in range(16):
-                acc2 = np.zeros((16, 64))
-                for s in range(15):
-                    mfma_bf16(ws.take(), P[8 * s:8 * s + 8].T, acc2)
-                H = pack_relu(acc2)
-                for s in range(2):
-                    for c3 in range(4):
-                        mfma_bf16(ws.take(), H[8 * s:8 * s + 8].T, acc3[c3])
-                ws.take()  # padding group
+            acc2, H = {}, {}
+            for kind, tile, idx in GEMM_ORDER:      # the stream order of the 1x1 pair (kGemmOrder)
+                w = ws.take()
+                if kind == 0:
+                    if idx == 0:
+                        acc2[tile] = np.zeros((16, 64))
+                    mfma_bf16(w, P[8 * idx:8 * idx + 8].T, acc2[tile])
+                elif kind == 1:
+                    if tile not in H:
+                        H[tile] = pack_relu(acc2[tile])
+                    s, c3 = idx >> 2, idx & 3
+                    mfma_bf16(w, H[tile][8 * s:8 * s + 8].T, acc3[c3])
             acc3_h.append(acc3)
         inter["x1"] = x1
         x3 = np.zeros((128, 64))

@@ -8,7 +8,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ACC: 0 accumulator in AGPRs, 1 in VGPRs.  BSRC: 0 B operand in VGPRs, 1 in AGPRs.
 // READS: ds_read_b128 per MFMA (0, 1 or 2; the second one is not consumed).  CHAINS: 1 or 2 accumulators in turn.
-template <int ACC, int BSRC, int READS, int CHAINS>
+template <int ACC, int BSRC, int READS, int CHAINS, int SAME = 0>
 __global__ __launch_bounds__(256, 1) void probe(float* out, int iters) {
     __shared__ f32x4 ring[4096];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -19,7 +19,8 @@ __global__ __launch_bounds__(256, 1) void probe(float* out, int iters) {
     f32x4 b = f32x4{0.5f, 0.25f, 1.f, 2.f};
     constexpr int LA = 4;
     f32x4 pre[LA + 1], junk[LA + 1];
-    const f32x4* rp = ring + ((wave + 1) & 3) * 1024 + lane;
+    // SAME: all four waves of the workgroup read the same fragments (as k_eval_bf16's waves do), else each its own quarter
+    const f32x4* rp = ring + (SAME ? 0 : ((wave + 1) & 3) * 1024) + lane;
     for (int i = 0; i < LA; ++i) pre[i] = rp[i * 64];
     for (int i = 0; i <= LA; ++i) junk[i] = b;
     long long t0 = __builtin_amdgcn_s_memtime();
@@ -45,11 +46,11 @@ __global__ __launch_bounds__(256, 1) void probe(float* out, int iters) {
     out[blockIdx.x * 256 + threadIdx.x] = s;
     if (threadIdx.x == 0 && blockIdx.x == 0) ((long long*)out)[1 << 20] = t1 - t0;
 }
-template <int ACC, int BSRC, int READS, int CHAINS>
+template <int ACC, int BSRC, int READS, int CHAINS, int SAME = 0>
 void run(const char* name, float* d) {
     const int iters = 100;
     for (int rep = 0; rep < 2; ++rep) {
-        hipLaunchKernelGGL((probe<ACC, BSRC, READS, CHAINS>), dim3(256), dim3(256), 0, 0, d, iters);
+        hipLaunchKernelGGL((probe<ACC, BSRC, READS, CHAINS, SAME>), dim3(256), dim3(256), 0, 0, d, iters);
         (void)hipDeviceSynchronize();
     }
     long long cyc;
@@ -71,5 +72,8 @@ int main() {
     run<0, 0, 2, 1>("acc AGPR, B VGPR, A from LDS + 1 more ds_read_b128, 1 chain", d);
     run<1, 0, 2, 1>("acc VGPR, B VGPR, A from LDS + 1 more ds_read_b128, 1 chain", d);
     run<1, 1, 2, 1>("acc VGPR, B AGPR, A from LDS + 1 more ds_read_b128, 1 chain", d);
+    run<1, 1, 1, 1, 1>("acc VGPR, B AGPR, A from LDS, 1 chain, all waves read the same fragments", d);
+    run<1, 1, 2, 1, 1>("acc VGPR, B AGPR, A + 1 more ds_read_b128, all waves the same fragments", d);
+    run<0, 0, 1, 1, 1>("acc AGPR, B VGPR, A from LDS, 1 chain, all waves read the same fragments", d);
     return 0;
 }
