@@ -82,7 +82,7 @@ constexpr int kConv59Groups = 5 * 9 * 2;  // 90
 constexpr int kGemmBase = kInputGroups;
 constexpr int kConvBase = kGemmBase + kC2Tiles * kPerC2Groups;          // 464
 constexpr int kStreamGroups = kConvBase + kConv4Groups + kConv59Groups;  // 626
-constexpr int kStreamChunkMax = 16;
+constexpr int kStreamChunkMax = 32;
 // The kernel walks the stream as a ring, board after board: padded to 640 groups = 40 chunks of 16,
 // a multiple of the ring's slot count and of the register look-ahead, so that every board starts in
 // the same ring phase; the prefetch wraps to group 0 instead of running past the end.

@@ -76,17 +76,13 @@ constexpr int SLOTS = BF16_SLOTS;           // ring slots: one being read, one j
 #define BF16_LA 7
 #endif
 constexpr int LA = BF16_LA;                       // groups held in registers ahead of the MFMA
-#ifndef BF16_C2U
-#define BF16_C2U 16
-#endif
-constexpr int C2_UNROLL = BF16_C2U;
+// Chunks the refill runs ahead of the chunk being read: with three or more slots the slot refilled at a
+// chunk barrier is that of the chunk before the one just finished (SLOTS-2 ahead); with two slots it is
+// the one just finished (one ahead), and the barrier also waits for this wave's own LDS reads.
+constexpr int AHEAD = SLOTS == 2 ? 1 : SLOTS - 2;
 static_assert(CHUNK <= kStreamChunkMax, "");
 static_assert(CHUNK % WAVES == 0, "every wave fetches whole groups");
-static_assert(kInputGroups % CHUNK == 0 && kInputGroups % (LA + 1) == 0, "the tile loop starts on a chunk boundary");
-static_assert((kPerC2Groups * C2_UNROLL) % CHUNK == 0 && (kPerC2Groups * C2_UNROLL) % (LA + 1) == 0,
-              "the loop body is whole chunks and keeps the look-ahead phase");
-static_assert(kC2Tiles % C2_UNROLL == 0, "");
-static_assert(LA <= CHUNK && SHARE <= CHUNK, "");
+static_assert(LA <= CHUNK && SHARE <= CHUNK && SLOTS >= 2, "");
 constexpr int WALK_CHUNKS = kStreamWalkGroups / CHUNK;   // chunks per board (the stream is walked as a ring)
 static_assert(kStreamWalkGroups % CHUNK == 0 && WALK_CHUNKS % SLOTS == 0 && kStreamWalkGroups % (LA + 1) == 0,
               "every board starts in the same phase of the ring and of the register look-ahead");
@@ -125,17 +121,18 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // slot refilled after the barrier is that of the chunk BEFORE the one just finished, whose reads
 // were issued more than CHUNK groups ago and have returned (LDS returns a wave's reads in order,
 // and every group waits for its own fragment, issued LA groups earlier, before its MFMAs).
-// EXTRA = 1 for the two barriers after the next board's mailbox prefetch (one more LDS-DMA, issued
+// EXTRA = 1 for the AHEAD barriers after the next board's mailbox prefetch (one more LDS-DMA, issued
 // right after a chunk's pieces): it is younger than the pieces those barriers need and may stay in
 // flight; the third barrier after it retires it (in order) with the pieces it waits for.
 template <int EXTRA>
 __device__ __forceinline__ void ring_barrier() {
-    constexpr int N = (SLOTS - 3) * SHARE + EXTRA;
-    static_assert(SLOTS >= 3 && N < 64, "vmcnt is a 6-bit counter");
+    constexpr int N = (AHEAD - 1) * SHARE + EXTRA;
+    static_assert(N < 64, "vmcnt is a 6-bit counter");
 #ifdef BF16_ABL_NOBAR
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 #else
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+    if (SLOTS == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 #endif
 }
 
@@ -189,12 +186,16 @@ struct WStream {
         sbase = reinterpret_cast<const unsigned char*>((uintptr_t)(((unsigned long long)hi << 32) | lo));
     }
     __device__ __forceinline__ void fetch_piece(int i) {
-        static_assert(SHARE <= 4, "immediate offsets of a global instruction reach 4095");
+        static_assert(SHARE <= 8, "two runs of four pieces: immediate offsets of a global instruction reach 4095");
+        if (i == 4) {   // second half of an 8-piece share: both sides 4 KiB on
+            asm volatile("s_add_u32 m0, m0, 0x1000\n\ts_nop 0" ::: "memory", "m0", "scc");
+            sbase += 4096;
+        }
 #ifndef BF16_ABL_NODMA
-        if (i == 0) asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase) : "memory");
-        if (i == 1) asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" ::"v"(voff), "s"(sbase) : "memory");
-        if (i == 2) asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" ::"v"(voff), "s"(sbase) : "memory");
-        if (i == 3) asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" ::"v"(voff), "s"(sbase) : "memory");
+        if ((i & 3) == 0) asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase) : "memory");
+        if ((i & 3) == 1) asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" ::"v"(voff), "s"(sbase) : "memory");
+        if ((i & 3) == 2) asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" ::"v"(voff), "s"(sbase) : "memory");
+        if ((i & 3) == 3) asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" ::"v"(voff), "s"(sbase) : "memory");
 #endif
     }
     // The wave's next board (32 mailbox bytes) into lds.next_mailbox by LDS-DMA: lanes 0-7 carry it,
@@ -211,7 +212,7 @@ struct WStream {
         sbase0 = sbase = reinterpret_cast<const unsigned char*>(stream + wave * SHARE * 64);
         voff = (unsigned)lane * 16u;
 #pragma unroll
-        for (int c = 0; c < SLOTS - 2; ++c) {
+        for (int c = 0; c < AHEAD; ++c) {
             set_m0(c * CHUNK * 64);
             set_base(c);
 #pragma unroll
@@ -219,12 +220,12 @@ struct WStream {
         }
         rd = (SLOTS - 1) * CHUNK * 64;
     }
-    // After the barrier every wave's share of chunk k is in LDS and nobody reads chunk k-2 any
-    // more, so its slot takes chunk k+SLOTS-2.
+    // After the barrier every wave's share of chunk k is in LDS and nobody reads chunk k-2 (k-1 with two
+    // slots) any more, so its slot takes chunk k+AHEAD.
     template <int EXTRA>
     __device__ __forceinline__ void next_chunk() {
         rd = (rd == (SLOTS - 1) * CHUNK * 64) ? 0 : rd + CHUNK * 64;
-        fill = rd + (SLOTS - 2) * CHUNK * 64;
+        fill = rd + AHEAD * CHUNK * 64;
         if (fill >= SLOTS * CHUNK * 64) fill -= SLOTS * CHUNK * 64;
         __builtin_amdgcn_sched_barrier(0);
         ring_barrier<EXTRA>();
@@ -233,7 +234,7 @@ struct WStream {
     }
     __device__ __forceinline__ void start() {
         next_chunk<0>();
-        set_base(SLOTS - 2);
+        set_base(AHEAD);
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
             if (i < SHARE) fetch_piece(i);
@@ -247,9 +248,9 @@ struct WStream {
     __device__ __forceinline__ bf16x8 take(int g) {
         const int nx = g + LA, i = nx % CHUNK;
         // the mailbox prefetch follows the take of group kPrefetchGroup: its two next barriers allow for it
-        const bool extra = nx > kPrefetchGroup + LA && nx <= kPrefetchGroup + LA + 2 * CHUNK;
+        const bool extra = nx > kPrefetchGroup + LA && nx <= kPrefetchGroup + LA + AHEAD * CHUNK;
         if (i == 0) { if (extra) next_chunk<1>(); else next_chunk<0>(); }
-        if (i == 0) set_base((nx / CHUNK + SLOTS - 2) % WALK_CHUNKS);
+        if (i == 0) set_base((nx / CHUNK + AHEAD) % WALK_CHUNKS);
         if (i < SHARE) fetch_piece(i);
 
 #ifndef BF16_ABL_NOAREAD

@@ -37,9 +37,8 @@ for i, nm in enumerate(names):
     print("%-8s median %9.0f  p10 %9.0f  p90 %9.0f   own MFMA cycles %7d" % (nm, np.median(d[:, :, i]), np.percentile(d[:, :, i], 10), np.percentile(d[:, :, i], 90), ideal[i]))
 span = t[:, :, 6].max() - t[:, :, 0].min()
 print("kernel span (stamp ticks)", span, " sum of wave lives / span = average waves in flight %.1f" % (life.sum() / span))
-ph = np.diff(raw[:, :, 8:14], axis=2)
-for i, nm in enumerate(["A G1 t0 (480)", "B G1 t1 (480)", "C G2 t0 (256)", "D G2 t1 (256)", "next tile (1472)"]):
-    print("%-18s median %7.0f p10 %7.0f p90 %7.0f" % (nm, np.median(ph[:, :, i]), np.percentile(ph[:, :, i], 10), np.percentile(ph[:, :, i], 90)))
+step = raw[:, :, 9] - raw[:, :, 8]
+print("one step of the 1x1 pair (23 groups, 46 MFMAs = 1472 cycles): median %.0f p10 %.0f p90 %.0f" % (np.median(step), np.percentile(step, 10), np.percentile(step, 90)))
 rt0, rt1 = raw[:, :, 7], raw[:, :, 14]
 rt_life = (rt1 - rt0).astype(np.float64)
 ok = rt_life > 0
