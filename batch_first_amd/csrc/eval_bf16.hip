@@ -81,7 +81,7 @@ constexpr int LA = BF16_LA;                       // groups held in registers ah
 // the one just finished (one ahead), and the barrier also waits for this wave's own LDS reads.
 constexpr int AHEAD = SLOTS == 2 ? 1 : SLOTS - 2;
 static_assert(CHUNK <= kStreamChunkMax, "");
-static_assert(CHUNK % WAVES == 0, "every wave fetches whole groups");
+static_assert(SHARE < CHUNK && CHUNK % WAVES == 0, "every wave fetches whole groups");
 static_assert(LA <= CHUNK && SHARE <= CHUNK && SLOTS >= 2, "");
 constexpr int WALK_CHUNKS = kStreamWalkGroups / CHUNK;   // chunks per board (the stream is walked as a ring)
 static_assert(kStreamWalkGroups % CHUNK == 0 && WALK_CHUNKS % SLOTS == 0 && kStreamWalkGroups % (LA + 1) == 0,
@@ -106,6 +106,7 @@ struct Lds {
     __attribute__((aligned(16))) unsigned char board[BPB][BOARD_BYTES];
     u32x4 onehot[16][2];                                 // stage 1: [code][lane half] -> 8 bf16 planes
     __attribute__((aligned(16))) float bias3[6][2][16];  // shifts of x4..x9 in accumulator order: [layer][lane half][register]
+    __attribute__((aligned(16))) float bias2[4][2][16];  // shifts of x3 the same way: [32-channel tile][lane half][register]
     f32x4 hpart[WAVES][64];                              // stage 5: per-wave partial sums of the 8x8 layer
     __attribute__((aligned(16))) unsigned char next_mailbox[WAVES][256];  // the wave's next board, prefetched by LDS-DMA
 };
@@ -199,8 +200,8 @@ struct WStream {
 #endif
     }
     // The wave's next board (32 mailbox bytes) into lds.next_mailbox by LDS-DMA: lanes 0-7 carry it,
-    // the others repeat it.  Call right after the last piece of a chunk (M0 is set again at the next
-    // chunk barrier) and use ring_barrier<1> at the next two barriers.
+    // the others repeat it.  Call right after the last piece of a chunk (M0 is set again by the
+    // next take: aim_refill) and use ring_barrier<1> at the next two barriers.
     __device__ __forceinline__ void prefetch_mailbox(const unsigned char* board_bytes, unsigned lds_dst, int lane) {
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2"
                      ::"s"(lds_dst), "v"((unsigned)(lane & 7) * 4u), "s"(board_bytes) : "memory", "m0");
@@ -221,23 +222,39 @@ struct WStream {
         rd = (SLOTS - 1) * CHUNK * 64;
     }
     // After the barrier every wave's share of chunk k is in LDS and nobody reads chunk k-2 (k-1 with two
-    // slots) any more, so its slot takes chunk k+AHEAD.
+    // slots) any more, so its slot takes chunk k+AHEAD.  Nothing but the barrier happens here: the pipe
+    // holds one MFMA (32 cycles) of work while the wave stands at it, so M0 and the scalar base of the
+    // refill were set in an MFMA gap of the chunk before (aim_refill).
     template <int EXTRA>
     __device__ __forceinline__ void next_chunk() {
         rd = (rd == (SLOTS - 1) * CHUNK * 64) ? 0 : rd + CHUNK * 64;
-        fill = rd + AHEAD * CHUNK * 64;
-        if (fill >= SLOTS * CHUNK * 64) fill -= SLOTS * CHUNK * 64;
         __builtin_amdgcn_sched_barrier(0);
         ring_barrier<EXTRA>();
-        set_m0(fill);
         __builtin_amdgcn_sched_barrier(0);
+    }
+    // M0 and scalar base for the refill that follows the NEXT chunk barrier: stream chunk `chunk` into
+    // the slot AHEAD + 1 after the one being read.  Called once the pieces of the current refill (and
+    // the mailbox prefetch, which borrows M0 right after them) have been issued.
+    __device__ __forceinline__ void aim_refill(int chunk) {
+        fill = rd + (AHEAD + 1) * CHUNK * 64;
+        while (fill >= SLOTS * CHUNK * 64) fill -= SLOTS * CHUNK * 64;
+        set_m0(fill);
+        set_base(chunk % WALK_CHUNKS);
+    }
+    // What the walk does at position i of the chunk being looked ahead into (chunk index c of the walk)
+    __device__ __forceinline__ void refill_step(int i, int c) {
+        if (i < SHARE) fetch_piece(i);
+        if (i == SHARE) aim_refill(c + 1 + AHEAD);
     }
     __device__ __forceinline__ void start() {
         next_chunk<0>();
+        fill = rd + AHEAD * CHUNK * 64;
+        if (fill >= SLOTS * CHUNK * 64) fill -= SLOTS * CHUNK * 64;
+        set_m0(fill);
         set_base(AHEAD);
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
-            if (i < SHARE) fetch_piece(i);
+            refill_step(i, 0);
             pre[i] = ring[rd + i * 64];
         }
     }
@@ -250,8 +267,7 @@ struct WStream {
         // the mailbox prefetch follows the take of group kPrefetchGroup: its two next barriers allow for it
         const bool extra = nx > kPrefetchGroup + LA && nx <= kPrefetchGroup + LA + AHEAD * CHUNK;
         if (i == 0) { if (extra) next_chunk<1>(); else next_chunk<0>(); }
-        if (i == 0) set_base((nx / CHUNK + AHEAD) % WALK_CHUNKS);
-        if (i < SHARE) fetch_piece(i);
+        refill_step(i, nx / CHUNK);
 
 #ifndef BF16_ABL_NOAREAD
         pre[nx % (LA + 1)] = ring[rd + i * 64];
@@ -284,6 +300,12 @@ __device__ __forceinline__ unsigned pack_relu(float a, float b) {
 __device__ __forceinline__ float bf16_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xFFFF0000u); }
 
+#ifndef BF_STAMP_P0
+#define BF_STAMP_P0 (15 + 23)   // stage 2, flat position of stamp 8: start of the second step
+#endif
+#ifndef BF_STAMP_LEN
+#define BF_STAMP_LEN 23         // groups between stamps 8 and 9
+#endif
 #ifdef BF_STAMPS
 #define BF_STAMP(i) do { if (lane == 0) stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -460,6 +482,8 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_bf16(const uint8_t* __restr
     }
     for (int i = tid; i < 6 * 32; i += THREADS)
         lds.bias3[i >> 5][(i >> 4) & 1][i & 15] = bias[kBiasX4 + 32 * (i >> 5) + rowmap(i & 15, (i >> 4) & 1)];
+    for (int i = tid; i < 4 * 32; i += THREADS)
+        lds.bias2[i >> 5][(i >> 4) & 1][i & 15] = bias[kBiasX3 + 32 * (i >> 5) + rowmap(i & 15, (i >> 4) & 1)];
     constexpr int SQW = 64 / WAVES;  // squares (k-steps of the head) per wave
     u32x4 ha[SQW];
     if (MODE != 2) {
@@ -472,6 +496,8 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_bf16(const uint8_t* __restr
     // vmcnt(0), i.e. behind every LDS-DMA piece in flight
     const float head_shift = MODE != 2 ? bias[kBiasX10 + (tid & 15)] : 0.0f;
     const float head_logit = MODE != 2 ? bias[kLogitW + (tid & 15)] : 0.0f;
+    // the wave's two zero-haloed activation planes, zeroed once (see the end of stage 1)
+    for (int i = lane; i < 2 * PLANE_BYTES / 16; i += 64) reinterpret_cast<u32x4*>(region)[i] = u32x4{0u, 0u, 0u, 0u};
     {   // the first board's mailbox directly (every later one is prefetched)
         const unsigned b0 = blockIdx.x * BPB + wave;
         const unsigned bc = b0 < n_boards ? b0 : n_boards - 1;
@@ -519,20 +545,27 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_bf16(const uint8_t* __restr
         const u32x4* tbl = &lds.onehot[0][hl];
         stage1<DBG>(ws, mbc, tbl, P, hl, ln, dbg_board);
     }
-    // The byte mailbox is dead (only this wave reads it): its space becomes the two zero-haloed planes.
+    // The byte mailbox is dead (only this wave reads it): its bytes are halo squares 0-7 of plane 0 again.
+    // Everything else in the two planes is either halo, zero since the workgroup started (the layers write
+    // interior squares only), or interior, which every layer overwrites before it is read.
     lds_order();
-    for (int i = lane; i < 2 * PLANE_BYTES / 16; i += 64) reinterpret_cast<u32x4*>(region)[i] = u32x4{0u, 0u, 0u, 0u};
+    static_assert(MB_WORDS * 4 <= 8 * POS_BYTES, "the mailbox covers squares of the first halo row only");
+    if (lane < 8 * POS_BYTES / 16) reinterpret_cast<u32x4*>(region)[lane] = u32x4{0u, 0u, 0u, 0u};
 
     BF_STAMP(2);
     // ---- stage 2: 1x1 236->512 (+ReLU) chained into 1x1 512->128 ---------------------------
+    // The 128-channel accumulators start from the shifts of x3, read from LDS (lds.bias2) four registers
+    // at a time in the gaps of the first tile's 236->512 groups: scalar loads here would sit between stage 1's
+    // last MFMA and stage 2's first with the matrix pipe idle, and turn LDS waits into lgkmcnt(0).
     f32x16 acc3[2][4];
-#pragma unroll
-    for (int c3 = 0; c3 < 4; ++c3)
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            acc3[0][c3][t] = pick(hl, bias[kBiasX3 + 32 * c3 + rowmap(t, 0)], bias[kBiasX3 + 32 * c3 + rowmap(t, 1)]);
-            acc3[1][c3][t] = acc3[0][c3][t];
-        }
+    auto load_shift = [&](int r) {   // r = 0..31: board tile, 32-channel tile, quarter
+        const int T = r >> 4, c3 = (r >> 2) & 3, q = r & 3;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&lds.bias2[c3][hl][4 * q]);
+        acc3[T][c3][4 * q + 0] = v.x;
+        acc3[T][c3][4 * q + 1] = v.y;
+        acc3[T][c3][4 * q + 2] = v.z;
+        acc3[T][c3][4 * q + 3] = v.w;
+    };
 
     // Software pipeline across the hidden layer's 32-channel tiles, in the stream order kGemmOrder: while
     // tile u+1's 15 groups of the 236->512 layer multiply (both board tiles share each fragment as it
@@ -545,20 +578,29 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_bf16(const uint8_t* __restr
         unsigned H[2][8];    // packed hidden tile: [board tile][dword], B operands of its 512->128 groups
         auto pack_piece = [&](int buf, int k) {   // k = 0..15: dwords 0-3 of tile 0, of tile 1, then dwords 4-7
             const int T = (k >> 2) & 1, j = (k & 3) + 4 * (k >> 3);
+#ifdef BF16_ABL_NOPACK   // timing ablation: the hidden tile is never packed (wrong scores)
+            asm volatile("" : "=v"(H[T][j]) : "v"(acc2[buf][T][2 * j]), "v"(acc2[buf][T][2 * j + 1]));
+#else
             H[T][j] = pack_relu(acc2[buf][T][2 * j], acc2[buf][T][2 * j + 1]);
+#endif
         };
 #pragma unroll
         for (int p = 0; p < kC2Tiles * kPerC2Groups; ++p) {
             const int g = kGemmBase + p;
             const int kind = kGemmOrder.kind[p], tile = kGemmOrder.tile[p], idx = kGemmOrder.idx[p];
-            if (p == 15 + 23) BF_STAMP(8);
-            if (p == 15 + 2 * 23) BF_STAMP(9);
+            if (p == BF_STAMP_P0) BF_STAMP(8);
+            if (p == BF_STAMP_P0 + BF_STAMP_LEN) BF_STAMP(9);
             const bf16x8 w = ws.take(g);
 #ifndef BF16_NO_PREFETCH
             if (g == kPrefetchGroup)
                 ws.prefetch_mailbox(mailbox + (size_t)next_board * kMailboxBytes,
                                     (unsigned)(uintptr_t)(lds_bytes)lds.next_mailbox[wave], lane);
 #endif
+            if (p < 11) {   // the first 512->128 group is at p = 19
+                load_shift(3 * p);
+                load_shift(3 * p + 1);
+                if (3 * p + 2 < 32) load_shift(3 * p + 2);
+            }
             if (kind == 0) {
 #pragma unroll
                 for (int T = 0; T < 2; ++T) {
@@ -576,6 +618,8 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_bf16(const uint8_t* __restr
             // packs of the tile whose 236->512 groups ended with the previous step
             if (p >= 15 && p < 15 + 15 * 23) {
                 const int u = (p - 15) / 23, j = (p - 15) % 23;
+                // (two dwords in each of groups 0-3 instead measured slower: a pack in group 0 waits out the
+                // MFMA-result hazard of the previous step's last groups)
                 const int first = j == 0 ? 0 : j == 1 ? 0 : j == 2 ? 3 : j == 3 ? 6 : 8 + (j - 4);
                 const int count = j == 0 ? 0 : j <= 2 ? 3 : j == 3 ? 2 : j <= 11 ? 1 : 0;
 #pragma unroll

@@ -12,6 +12,8 @@ lib = ctypes.CDLL(os.path.join(ROOT, path))
 for fn, (res, argt) in _lib.SIGNATURES.items():
     getattr(lib, fn).restype = res; getattr(lib, fn).argtypes = argt
 blob = weights.to_blob(weights.make_weights())
+if os.environ.get("BF_ZERO_WEIGHTS"):   # diagnostic: data-dependent power (operand toggling) against the same instruction stream
+    blob = np.zeros_like(blob)
 ctx = ctypes.c_void_p(); assert lib.bf_ctx_create_ex(ctypes.byref(ctx), 0, blob.ctypes.data, blob.size, 1) == 0
 structs = positions.to_compact(positions.random_structs(n, seed=5))
 recs = torch.from_numpy(np.ascontiguousarray(structs).view(np.uint8).reshape(n, -1).copy()).cuda()
