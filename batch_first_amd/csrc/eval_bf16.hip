@@ -366,7 +366,10 @@ __device__ __forceinline__ void s1_pack_piece(int I, int piece, const f32x16 (&a
     const int half = kX1RegCount[I] / 2;
     const int T = piece / half, d = piece % half;
     const int tile = (2 * d) / 16, t = (2 * d) % 16;
-    const unsigned p = pack_relu(acc[T][tile][t], acc[T][tile][t + 1]);
+    unsigned p = pack_relu(acc[T][tile][t], acc[T][tile][t + 1]);
+    // pinned here: with nothing but later uses, the compiler sinks all 120 packs past stage 1's last MFMA
+    // into the block where stage 2 starts, and the matrix pipe waits for them
+    asm volatile("" : "+v"(p));
     P[T][kX1RegBase[I] / 2 + d] = p;
     if (DBG) {
         const int c0 = 2 * (2 * d) + hl, c1 = 2 * (2 * d + 1) + hl;  // local channels of the pair
@@ -522,7 +525,10 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_bf16(const uint8_t* __restr
 #endif
 
     // ---- byte mailbox: 15 everywhere, then the board's codes ---------------------------------
-    for (int i = lane; i < MB_WORDS; i += 64) reinterpret_cast<unsigned*>(region)[i] = 0x0F0F0F0Fu;
+    // (two unconditional stores, 512 bytes: the four words past the mailbox are halo bytes zeroed again after stage 1)
+    static_assert(MB_WORDS <= 128, "");
+    reinterpret_cast<unsigned*>(region)[lane] = 0x0F0F0F0Fu;
+    reinterpret_cast<unsigned*>(region)[lane + 64] = 0x0F0F0F0Fu;
     lds_order();
     {
 #ifndef BF16_NO_PREFETCH
@@ -549,8 +555,11 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_bf16(const uint8_t* __restr
     // Everything else in the two planes is either halo, zero since the workgroup started (the layers write
     // interior squares only), or interior, which every layer overwrites before it is read.
     lds_order();
-    static_assert(MB_WORDS * 4 <= 8 * POS_BYTES, "the mailbox covers squares of the first halo row only");
-    if (lane < 8 * POS_BYTES / 16) reinterpret_cast<u32x4*>(region)[lane] = u32x4{0u, 0u, 0u, 0u};
+    // One unconditional 1-KiB write (no branch: a new basic block here is where the compiler would sink
+    // stage 1's packs to): squares 0-15 of plane 0, i.e. the mailbox bytes in the first halo row and a few
+    // squares after it that hold nothing live at this point.
+    static_assert(MB_WORDS * 4 <= 1024 && 1024 <= PLANE_BYTES, "");
+    reinterpret_cast<u32x4*>(region)[lane] = u32x4{0u, 0u, 0u, 0u};
 
     BF_STAMP(2);
     // ---- stage 2: 1x1 236->512 (+ReLU) chained into 1x1 512->128 ---------------------------
