@@ -32,7 +32,7 @@ PEAK_HBM_GBS = 8000.0
 # under profiles/ (FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes; see
 # tools/pmc_summary.py).  Counters cannot be read from inside this process, so the figure is the
 # committed measurement of the same kernel and batch, not a live one.
-TRAFFIC_PROFILES = {"f32": "profiles/r1/pmc_k_eval_f32_v7.json", "bf16": "profiles/r1/pmc_k_eval_bf16_v7.json"}
+TRAFFIC_PROFILES = {"f32": "profiles/r1/pmc_k_eval_f32_v8.json", "bf16": "profiles/r1/pmc_k_eval_bf16_v8.json"}
 
 
 def profiled_traffic(dtype):
