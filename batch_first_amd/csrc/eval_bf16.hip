@@ -307,7 +307,9 @@ __device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast
 #define BF_STAMP_LEN 23         // groups between stamps 8 and 9
 #endif
 #ifdef BF_STAMPS
-#define BF_STAMP(i) do { if (lane == 0) stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+// wave-uniform, low 32 bits, no branch: a conditional store would split the board loop's basic block
+// (and the compiler sinks work into the new blocks), 64-bit per-lane stamps made the kernel spill
+#define BF_STAMP(i) do { stamps[i] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define BF_STAMP(i) ((void)0)
 #endif
@@ -386,7 +388,10 @@ __device__ __forceinline__ void s1_pack_piece(int I, int piece, const f32x16 (&a
 template <bool DBG>
 __device__ __forceinline__ void stage1(WStream& ws, const unsigned char* mbc, const u32x4* tbl, unsigned (&P)[2][kX1Dwords],
                                        int hl, int ln, float* dbg_board) {
-    constexpr int CQ = 2, BQ = 2, NC = CQ + BQ;
+#ifndef BF16_S1_Q
+#define BF16_S1_Q 2
+#endif
+    constexpr int CQ = BF16_S1_Q, BQ = BF16_S1_Q, NC = CQ + BQ;
     int code[NC][2];
     u32x4 b[BQ][2];
     f32x16 acc[2][2][2];  // [conv parity][board tile][channel tile]
@@ -466,7 +471,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_bf16(const uint8_t* __restr
     typedef __attribute__((address_space(3))) unsigned char* lds_bytes;
 
 #ifdef BF_STAMPS
-    long long stamps[16];
+    unsigned stamps[16] = {};
 #endif
     WStream ws;
     ws.prime(wstream, &lds.wring[0][0][0], lane, wave);
@@ -521,7 +526,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_bf16(const uint8_t* __restr
     ws.board_start();
     BF_STAMP(0);
 #ifdef BF_STAMPS
-    if (lane == 0) stamps[7] = __builtin_amdgcn_s_memrealtime();  // constant 100 MHz clock, common to the chip
+    stamps[7] = (unsigned)__builtin_amdgcn_s_memrealtime();  // constant 100 MHz clock, common to the chip
 #endif
 
     // ---- byte mailbox: 15 everywhere, then the board's codes ---------------------------------
@@ -692,7 +697,11 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_bf16(const uint8_t* __restr
         const int tap = idx >> 1, s = idx & 1;
         return *reinterpret_cast<const u32x4*>(region + (c & 1) * PLANE_BYTES + raddr[tap / 3][s] + T * TILE1 + (tap % 3) * POS_BYTES);
     };
-    constexpr int D = 4, NSLOTS = 9 * 36;
+#ifndef BF16_CONV_D
+#define BF16_CONV_D 4
+#endif
+    constexpr int D = BF16_CONV_D, NSLOTS = 9 * 36;   // B operands read D slots ahead
+    static_assert(D == 4, "a read further ahead passes the write_piece of its input (D = 8: wrong scores, and no faster)");
     f32x16 A[2][2];   // [set][tile]: chunks 0..3 accumulate in set 0, layer c >= 4 in set (c & 1) ^ 1
     f32x16 bs;        // shift of the layer about to start
     u32x4 bq[D];
@@ -812,14 +821,14 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_bf16(const uint8_t* __restr
     }
     BF_STAMP(6);
 #ifdef BF_STAMPS
-    if (lane == 0) stamps[14] = __builtin_amdgcn_s_memrealtime();
+    stamps[14] = (unsigned)__builtin_amdgcn_s_memrealtime();
 #endif
     }  // board loop
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring's look-ahead DMA must not outlive the workgroup
 #ifdef BF_STAMPS
     if (!DBG && dbg && lane == 0) {   // stamps of the workgroup's last board
         long long* out = reinterpret_cast<long long*>(dbg) + ((size_t)blockIdx.x * WAVES + wave) * 16;
-        for (int i = 0; i < 15; ++i) out[i] = stamps[i];
+        for (int i = 0; i < 15; ++i) out[i] = (long long)stamps[i];   // low 32 bits: differences are taken modulo 2^32
     }
 #endif
 }

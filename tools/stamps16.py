@@ -29,21 +29,18 @@ waves = bpb
 # persistent workgroups: one per compute unit, stamps are those of each workgroup's last board quad
 blocks = min((n + bpb - 1) // bpb, torch.cuda.get_device_properties(0).multi_processor_count)
 raw = dbg.view(-1)[: blocks * waves * 16 * 2].cpu().numpy().view(np.int64).reshape(blocks, waves, 16)
+M = (1 << 32) - 1   # the kernel keeps the low 32 bits of each stamp
 t = raw[:, :, :7]
-d = np.diff(t, axis=2)
+d = np.diff(t, axis=2) & M
 names = ["setup", "stage1", "gemm", "conv4", "conv5-9", "head"]
 ideal = [0, 160 * 32, 16 * 46 * 32, 144 * 32, 180 * 32, 0]
-life = t[:, :, 6] - t[:, :, 0]
+life = (t[:, :, 6] - t[:, :, 0]) & M
 print("blocks", blocks, "wave life median %.0f  own MFMA cycles %d" % (np.median(life), sum(ideal)))
 for i, nm in enumerate(names):
     print("%-8s median %9.0f  p10 %9.0f  p90 %9.0f   own MFMA cycles %7d" % (nm, np.median(d[:, :, i]), np.percentile(d[:, :, i], 10), np.percentile(d[:, :, i], 90), ideal[i]))
-span = t[:, :, 6].max() - t[:, :, 0].min()
-print("kernel span (stamp ticks)", span, " sum of wave lives / span = average waves in flight %.1f" % (life.sum() / span))
-step = raw[:, :, 9] - raw[:, :, 8]
+step = (raw[:, :, 9] - raw[:, :, 8]) & M
 print("one step of the 1x1 pair (23 groups, 46 MFMAs = 1472 cycles): median %.0f p10 %.0f p90 %.0f" % (np.median(step), np.percentile(step, 10), np.percentile(step, 90)))
 rt0, rt1 = raw[:, :, 7], raw[:, :, 14]
-rt_life = (rt1 - rt0).astype(np.float64)
+rt_life = ((rt1 - rt0) & M).astype(np.float64)
 ok = rt_life > 0
 print("stamp ticks per 100 MHz tick: median %.2f  => stamp clock %.3f GHz" % (np.median(life[ok] / rt_life[ok]), np.median(life[ok] / rt_life[ok]) * 0.1))
-span_rt = rt1.max() - rt0.min()
-print("last board quads: span %.1f us (100 MHz clock)" % (span_rt / 100.0))
