@@ -173,10 +173,17 @@ struct WStream {
     }
     // The scalar base of a chunk's pieces is computed where the chunk's refill starts, by two scalar adds
     // the compiler cannot hoist.  Left to itself it keeps all 40 chunk bases of a board in SGPRs for the
-    // whole kernel and spills ~30 other SGPRs to VGPR lanes; builds of that form faulted on the GPU
-    // (memory aperture violation) whenever one of those bases stayed live from the first refill to the
-    // walk's last one, with every address in the ISA correct as far as it could be read -- cause not
-    // established; this form has no such long-lived registers and at most one spilled pair.
+    // whole kernel and spills SGPRs to VGPR lanes.  Round-1 builds of that form faulted on the GPU (memory
+    // aperture violation).  Cause (profiles/r2/aperture_violation_isa.txt): a spilled base came back by
+    //     v_readlane_b32 s2, v255, 13 / v_readlane_b32 s3, v255, 14 / global_load_lds_dwordx4 v252, s[2:3]
+    // with no wait state between.  A vector-memory instruction that reads an SGPR written by a VALU
+    // instruction needs five; hipcc pads that pair for its own loads, but an asm block is opaque to its
+    // hazard recogniser, so the DMA issued with the pair's previous contents as its 64-bit base.
+    // INVARIANT: no VALU write of an SGPR within five wait states in front of an asm vector-memory
+    // instruction that reads it, and no compiler write of M0.  This form meets it by construction where it
+    // can (the base comes out of scalar adds, which need no wait states, and is consumed within the same
+    // chunk; sgpr_spill_count is 0), and the Makefile checks the listing of every build for it
+    // (tools/isa_hazards.py): a build that breaks it yields no object file.
     __device__ __forceinline__ void set_base(int chunk) {
         const unsigned long long b0 = (unsigned long long)(uintptr_t)sbase0;
         unsigned lo, hi;
