@@ -43,6 +43,12 @@ SIGNATURES = {
     "bf_ctx_check": (_int, [_vp, _vp]),
     "bf_eval_wire_host": (_int, [_vp, _vp, _sz, _vp, _sz, _vp]),
     "bf_eval_structs_host": (_int, [_vp, _vp, _sz, _vp, _sz, _vp, _c.POINTER(_sz)]),
+    "bf_multi_create": (_int, [_c.POINTER(_vp), _c.POINTER(_vp), _sz, _sz]),
+    "bf_multi_destroy": (None, [_vp]),
+    "bf_multi_devices": (_sz, [_vp]),
+    "bf_multi_eval_wire_host": (_int, [_vp, _vp, _sz, _vp, _sz, _vp]),
+    "bf_multi_eval_structs_host": (_int, [_vp, _vp, _sz, _vp, _sz, _vp, _c.POINTER(_sz)]),
+    "bf_host_split_wire": (_int, [_vp, _sz, _sz, _vp, _vp]),
     "bf_host_encode_wire": (_int, [_vp, _sz, _vp, _sz, _vp, _vp, _c.POINTER(_sz), _c.POINTER(_sz)]),
     "bf_packed_floats": (_sz, []),
     "bf_pack_weights": (_int, [_vp, _sz, _vp, _sz]),

@@ -175,7 +175,109 @@ class BoardPredictor:
             pass
 
 
-def get_inference_functions(weights, session_gpu_memory=.4, device=0, dtype="f32", policy_weights=None):
+class MultiDevicePredictor:
+    """The same callable over several GPUs of the node: one :class:`BoardPredictor` (one bf_ctx, one
+    stream) per device behind a ``bf_multi`` handle.  Every batch is cut into contiguous shards, the
+    wire format at sum-of-popcount boundaries (a shard may begin on an odd nibble); all
+    shards are enqueued from the calling thread before any is waited for, and one ``float32[N]`` comes
+    back in board order.  Scores are bit-identical to a single device's: a board's score does not
+    depend on its place in a batch.  The move-scoring network stays on the first device."""
+
+    def __init__(self, weights, devices, dtype="f32", min_shard=1024, allow_repeats=False):
+        devices = [int(d) for d in devices]
+        # allow_repeats: several contexts (streams) on one GPU -- how a one-GPU box runs this path in tests
+        if not devices or (len(set(devices)) != len(devices) and not allow_repeats):
+            raise ValueError("devices must be a non-empty list of distinct GPU indices")
+        self._lib = _lib.load()
+        blob = _as_blob(weights)
+        self.parts = []
+        try:
+            for d in devices:
+                self.parts.append(BoardPredictor(blob, device=d, dtype=dtype))
+            arr = (ctypes.c_void_p * len(self.parts))(*[p._ctx for p in self.parts])
+            handle = ctypes.c_void_p()
+            _lib.check(self._lib.bf_multi_create(ctypes.byref(handle), arr, len(self.parts), int(min_shard)))
+        except Exception:
+            for p in self.parts:
+                p.close()
+            raise
+        self._multi = handle
+        self.devices = devices
+        self.device = devices[0]
+        self.dtype = self.parts[0].dtype
+        self._closed = False
+        self._close_lock = threading.Lock()
+
+    @property
+    def has_policy(self):
+        return self.parts[0].has_policy
+
+    def _multi_handle(self):
+        if self._closed:
+            raise RuntimeError("the evaluator has been closed")
+        return self._multi
+
+    def _handle(self):
+        """The first device's context (the move-scoring network lives there)."""
+        self._multi_handle()
+        return self.parts[0]._handle()
+
+    def __call__(self, piece_filters, occupied_bbs):
+        m = self._multi_handle()
+        pf, occ = _wire_arrays(piece_filters, occupied_bbs)
+        scores = np.empty(occ.size, dtype=np.float32)
+        if occ.size == 0:
+            if pf.size:
+                raise ValueError("piece_filters given without boards")
+            return scores
+        _lib.check(self._lib.bf_multi_eval_wire_host(m, pf.ctypes.data, pf.size, occ.ctypes.data, occ.size, scores.ctypes.data))
+        return scores
+
+    def eval_structs(self, struct_array, to_score_mask=None):
+        m = self._multi_handle()
+        recs = np.ascontiguousarray(struct_array)
+        if recs.ndim != 1 or recs.dtype.itemsize < 82:
+            raise ValueError("struct_array must be a 1-d array of node records (>= 82 bytes each)")
+        n, mask_ptr, count = recs.size, None, recs.size
+        if to_score_mask is not None:
+            mask = np.ascontiguousarray(to_score_mask, dtype=np.bool_).view(np.uint8)
+            if mask.shape != (n,):
+                raise ValueError("to_score_mask must have one entry per record")
+            mask_ptr, count = mask.ctypes.data, int(np.count_nonzero(mask))
+        scores = np.empty(count, dtype=np.float32)
+        if count == 0:
+            return scores
+        done = ctypes.c_size_t(0)
+        _lib.check(self._lib.bf_multi_eval_structs_host(m, recs.ctypes.data, recs.dtype.itemsize, mask_ptr, n,
+                                                        scores.ctypes.data, ctypes.byref(done)))
+        if done.value != count:
+            raise _lib.BatchFirstError("evaluated %d boards, expected %d" % (done.value, count))
+        return scores
+
+    def set_policy(self, policy_weights):
+        self.parts[0].set_policy(policy_weights)
+
+    def start_move_prediction(self, piece_filters, occupied_bbs):
+        return self.parts[0].start_move_prediction(piece_filters, occupied_bbs)
+
+    def close(self):
+        with self._close_lock:
+            if not self._closed:
+                self._closed = True
+                self._lib.bf_multi_destroy(self._multi)
+                self._multi = None
+                for p in self.parts:
+                    p.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def get_inference_functions(weights, session_gpu_memory=.4, device=0, dtype="f32", policy_weights=None, devices=None,
+                            min_shard=1024):
     """(board_predictor, start_move_prediction, closer_fn), as batch_first/chestimator.py:51-74.
 
     ``weights`` stands where ``graphdef_filename`` does: a frozen GraphDef file (``.pb`` binary or
@@ -186,14 +288,19 @@ def get_inference_functions(weights, session_gpu_memory=.4, device=0, dtype="f32
     (TensorFlow's allocator fraction has no counterpart here).  ``dtype``: "f32" (the parity path)
     or "bf16" (bf16 operands, float32 sums; include/batchfirst.h, BF_PRECISION_BF16), for both
     networks.  ``policy_weights``: the move-scoring network's blob (weights.to_policy_blob), file
-    or dict.
+    or dict.  ``devices``: a list of GPU indices turns ``board_predictor`` into one callable over all
+    of them (:class:`MultiDevicePredictor`: contiguous shards, one stream per device, scores gathered
+    to the caller; batches under ``min_shard`` boards per device use fewer devices).
     """
     del session_gpu_memory
     if isinstance(weights, (str, os.PathLike)) and _graphdef.is_graphdef_path(weights):
         weights, graph_policy = _graphdef.blobs_from_graphdef(weights)
         if policy_weights is None:
             policy_weights = graph_policy
-    board_predictor = BoardPredictor(weights, device=device, dtype=dtype)
+    if devices is not None:
+        board_predictor = MultiDevicePredictor(weights, devices, dtype=dtype, min_shard=min_shard)
+    else:
+        board_predictor = BoardPredictor(weights, device=device, dtype=dtype)
     if policy_weights is not None:
         board_predictor.set_policy(policy_weights)
 

@@ -29,6 +29,12 @@ struct Lane {
     unsigned* d_local_off = nullptr;
     unsigned* d_block_total = nullptr;
     uint8_t* d_mailbox = nullptr;
+    // Kernels of different calls share this scratch, and calls may come on different streams (the
+    // caller's for the device entry points, `stream` below for the host ones): the last kernel that
+    // touches it records `scratch_done` on its stream, and the next call makes its stream wait for
+    // that event before it enqueues anything.  Both happen under `mu`, so the order is total.
+    hipEvent_t scratch_done = nullptr;
+    bool scratch_used = false;
     // host entry points: own stream, pinned staging, device staging
     hipStream_t stream = nullptr;
     size_t cap_in_bytes = 0;
@@ -115,6 +121,18 @@ hipError_t launch_eval(bf_ctx* c, const uint8_t* d_mailbox, size_t n, float* d_s
 
 bf::Workspace workspace(Lane* c) { return bf::Workspace{c->d_local_off, c->d_block_total, c->d_err}; }
 
+// Call with the lane's mutex held, before enqueuing work that reads or writes the lane's scratch on
+// stream `s` / after the last such kernel has been enqueued (see Lane::scratch_done).
+int scratch_acquire(Lane* c, hipStream_t s) {
+    if (c->scratch_used) BF_HIP(hipStreamWaitEvent(s, c->scratch_done, 0));
+    return BF_OK;
+}
+int scratch_release(Lane* c, hipStream_t s) {
+    BF_HIP(hipEventRecord(c->scratch_done, s));
+    c->scratch_used = true;
+    return BF_OK;
+}
+
 int read_err_flag(Lane* c, hipStream_t s) {
     int flag = 0;
     BF_HIP(hipMemcpyAsync(&flag, c->d_err, sizeof flag, hipMemcpyDeviceToHost, s));
@@ -193,6 +211,8 @@ extern "C" int bf_ctx_create_ex(bf_ctx** out, int device, const float* h_weights
             return bail(bf::fail(BF_E_HIP, "bf_ctx_create: flag allocation failed"));
         if (hipStreamCreateWithFlags(&lane->stream, hipStreamNonBlocking) != hipSuccess)
             return bail(bf::fail(BF_E_HIP, "bf_ctx_create: stream creation failed"));
+        if (hipEventCreateWithFlags(&lane->scratch_done, hipEventDisableTiming) != hipSuccess)
+            return bail(bf::fail(BF_E_HIP, "bf_ctx_create: event creation failed"));
     }
     *out = c;
     return BF_OK;
@@ -206,6 +226,7 @@ extern "C" void bf_ctx_destroy(bf_ctx* c) {
             (void)hipStreamSynchronize(lane->stream);
             (void)hipStreamDestroy(lane->stream);
         }
+        if (lane->scratch_done) (void)hipEventDestroy(lane->scratch_done);
         if (lane->d_err) (void)hipFree(lane->d_err);
         if (lane->d_local_off) (void)hipFree(lane->d_local_off);
         if (lane->d_block_total) (void)hipFree(lane->d_block_total);
@@ -233,8 +254,9 @@ extern "C" int bf_encode_mailbox_wire(bf_ctx* c, const uint8_t* d_pf, size_t n_b
     DeviceGuard guard(c->device);
     std::lock_guard<std::mutex> lock(c->mu);
     if (int r = ensure_boards(c, n)) return r;
+    if (int r = scratch_acquire(c, (hipStream_t)stream)) return r;
     BF_HIP(bf::launch_mailbox_from_wire(d_pf, n_bytes, d_occ, n, workspace(c), d_mailbox, (hipStream_t)stream));
-    return BF_OK;
+    return scratch_release(c, (hipStream_t)stream);
 }
 
 extern "C" int bf_encode_mailbox_structs(bf_ctx* c, const void* d_structs, size_t stride, size_t n,
@@ -256,8 +278,9 @@ extern "C" int bf_encode_planes_wire(bf_ctx* c, const uint8_t* d_pf, size_t n_by
     DeviceGuard guard(c->device);
     std::lock_guard<std::mutex> lock(c->mu);
     if (int r = ensure_boards(c, n)) return r;
+    if (int r = scratch_acquire(c, (hipStream_t)stream)) return r;
     BF_HIP(bf::launch_planes_from_wire(d_pf, n_bytes, d_occ, n, workspace(c), d_planes, (hipStream_t)stream));
-    return BF_OK;
+    return scratch_release(c, (hipStream_t)stream);
 }
 
 extern "C" int bf_encode_planes_structs(bf_ctx* c, const void* d_structs, size_t stride, size_t n, float* d_planes,
@@ -288,9 +311,10 @@ extern "C" int bf_eval_wire(bf_ctx* c, const uint8_t* d_pf, size_t n_bytes, cons
     DeviceGuard guard(c->device);
     std::lock_guard<std::mutex> lock(c->mu);
     if (int r = ensure_boards(c, n)) return r;
+    if (int r = scratch_acquire(c, (hipStream_t)stream)) return r;
     BF_HIP(bf::launch_mailbox_from_wire(d_pf, n_bytes, d_occ, n, workspace(c), c->d_mailbox, (hipStream_t)stream));
     BF_HIP(launch_eval(c, c->d_mailbox, n, d_scores, nullptr, (hipStream_t)stream));
-    return BF_OK;
+    return scratch_release(c, (hipStream_t)stream);
 }
 
 extern "C" int bf_eval_structs(bf_ctx* c, const void* d_structs, size_t stride, size_t n, float* d_scores,
@@ -302,9 +326,10 @@ extern "C" int bf_eval_structs(bf_ctx* c, const void* d_structs, size_t stride, 
     DeviceGuard guard(c->device);
     std::lock_guard<std::mutex> lock(c->mu);
     if (int r = ensure_boards(c, n)) return r;
+    if (int r = scratch_acquire(c, (hipStream_t)stream)) return r;
     BF_HIP(bf::launch_mailbox_from_structs(d_structs, stride, n, c->d_mailbox, (hipStream_t)stream));
     BF_HIP(launch_eval(c, c->d_mailbox, n, d_scores, nullptr, (hipStream_t)stream));
-    return BF_OK;
+    return scratch_release(c, (hipStream_t)stream);
 }
 
 extern "C" int bf_eval_mailbox_debug(bf_ctx* c, const uint8_t* d_mailbox, size_t n, float* d_scores, float* d_debug,
@@ -346,10 +371,12 @@ extern "C" int bf_eval_wire_host(bf_ctx* c, const uint8_t* h_pf, size_t n_bytes,
     if (int r = ensure_staging(c, pf_off + n_bytes + 16, n)) return r;
     std::memcpy(c->h_in, h_occ, occ_bytes);
     if (n_bytes) std::memcpy(c->h_in + pf_off, h_pf, n_bytes);
+    if (int r = scratch_acquire(c, c->stream)) return r;
     BF_HIP(hipMemcpyAsync(c->d_in, c->h_in, pf_off + n_bytes, hipMemcpyHostToDevice, c->stream));
     BF_HIP(bf::launch_mailbox_from_wire(c->d_in + pf_off, n_bytes, reinterpret_cast<const uint64_t*>(c->d_in), n,
                                         workspace(c), c->d_mailbox, c->stream));
     BF_HIP(launch_eval(c, c->d_mailbox, n, c->d_scores, nullptr, c->stream));
+    if (int r = scratch_release(c, c->stream)) return r;
     BF_HIP(hipMemcpyAsync(c->h_scores, c->d_scores, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     if (int r = read_err_flag(c, c->stream)) return r;
     std::memcpy(h_scores, c->h_scores, n * sizeof(float));
@@ -383,14 +410,188 @@ extern "C" int bf_eval_structs_host(bf_ctx* c, const void* h_structs, size_t str
         std::memcpy(c->h_in + k * kCompact, recs + j * stride, BF_NODE_EVAL_BYTES);
         ++k;
     }
+    if (int r = scratch_acquire(c, c->stream)) return r;
     BF_HIP(hipMemcpyAsync(c->d_in, c->h_in, m * kCompact, hipMemcpyHostToDevice, c->stream));
     BF_HIP(bf::launch_mailbox_from_structs(c->d_in, kCompact, m, c->d_mailbox, c->stream));
     BF_HIP(launch_eval(c, c->d_mailbox, m, c->d_scores, nullptr, c->stream));
+    if (int r = scratch_release(c, c->stream)) return r;
     BF_HIP(hipMemcpyAsync(c->h_scores, c->d_scores, m * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     BF_HIP(hipStreamSynchronize(c->stream));
     std::memcpy(h_scores, c->h_scores, m * sizeof(float));
     if (n_scored) *n_scored = m;
     return BF_OK;
+}
+
+
+// ---- several GPUs behind one call (north_star: independent boards on each GPU on separate HIP streams,
+// scores gathered back to the search host; SURVEY.md 8(e): one process driving the devices) ---------
+
+struct bf_multi {
+    std::vector<bf_ctx*> ctx;      // one context per device, borrowed (the caller destroys them)
+    size_t min_shard = 1024;       // a device is used only if every device in use gets at least this many boards
+    std::mutex mu;                 // one multi-device call at a time (the contexts may still be used directly)
+    std::vector<size_t> board_lo, nibble_lo;   // scratch of the call in flight
+};
+
+extern "C" int bf_multi_create(bf_multi** out, bf_ctx* const* ctxs, size_t n_ctx, size_t min_shard) {
+    if (!out || !ctxs || n_ctx == 0) return bf::fail(BF_E_ARG, "bf_multi_create: no contexts");
+    *out = nullptr;
+    for (size_t i = 0; i < n_ctx; ++i) {
+        if (!ctxs[i]) return bf::fail(BF_E_ARG, "bf_multi_create: context %zu is null", i);
+        if (ctxs[i]->precision != ctxs[0]->precision)
+            return bf::fail(BF_E_ARG, "bf_multi_create: contexts differ in precision (scores would depend on the shard)");
+        for (size_t j = 0; j < i; ++j)
+            if (ctxs[j] == ctxs[i]) return bf::fail(BF_E_ARG, "bf_multi_create: context %zu given twice", i);
+    }
+    bf_multi* m = new (std::nothrow) bf_multi;
+    if (!m) return bf::fail(BF_E_ARG, "bf_multi_create: out of host memory");
+    m->ctx.assign(ctxs, ctxs + n_ctx);
+    m->min_shard = min_shard ? min_shard : 1;
+    *out = m;
+    return BF_OK;
+}
+
+extern "C" void bf_multi_destroy(bf_multi* m) { delete m; }
+
+extern "C" size_t bf_multi_devices(const bf_multi* m) { return m ? m->ctx.size() : 0; }
+
+namespace {
+
+size_t parts_for(const bf_multi* m, size_t n) {
+    size_t parts = n / m->min_shard;
+    if (parts < 1) parts = 1;
+    return parts < m->ctx.size() ? parts : m->ctx.size();
+}
+
+// Enqueue one shard's host-to-device copy, kernels and device-to-host copy on its context's stream.
+// The context's mutex is held by the caller until finish_shard().
+int start_wire_shard(bf_ctx* c, const uint8_t* h_pf, size_t n_bytes, unsigned start_nibble, const uint64_t* h_occ, size_t n) {
+    DeviceGuard guard(c->device);
+    if (!guard.ok) return bf::fail(BF_E_HIP, "hipSetDevice(%d) failed", c->device);
+    if (int r = ensure_boards(c, n)) return r;
+    const size_t occ_bytes = n * sizeof(uint64_t);
+    const size_t pf_off = (occ_bytes + 15) & ~(size_t)15;
+    if (int r = ensure_staging(c, pf_off + n_bytes + 16, n)) return r;
+    std::memcpy(c->h_in, h_occ, occ_bytes);
+    if (n_bytes) std::memcpy(c->h_in + pf_off, h_pf, n_bytes);
+    if (int r = scratch_acquire(c, c->stream)) return r;
+    BF_HIP(hipMemcpyAsync(c->d_in, c->h_in, pf_off + n_bytes, hipMemcpyHostToDevice, c->stream));
+    BF_HIP(bf::launch_mailbox_from_wire(c->d_in + pf_off, n_bytes, reinterpret_cast<const uint64_t*>(c->d_in), n,
+                                        workspace(c), c->d_mailbox, c->stream, start_nibble));
+    BF_HIP(launch_eval(c, c->d_mailbox, n, c->d_scores, nullptr, c->stream));
+    if (int r = scratch_release(c, c->stream)) return r;
+    BF_HIP(hipMemcpyAsync(c->h_scores, c->d_scores, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    return BF_OK;
+}
+
+int start_struct_shard(bf_ctx* c, const unsigned char* compact, size_t m) {
+    constexpr size_t kCompact = 88;
+    DeviceGuard guard(c->device);
+    if (!guard.ok) return bf::fail(BF_E_HIP, "hipSetDevice(%d) failed", c->device);
+    if (int r = ensure_boards(c, m)) return r;
+    if (int r = ensure_staging(c, m * kCompact, m)) return r;
+    std::memcpy(c->h_in, compact, m * kCompact);
+    if (int r = scratch_acquire(c, c->stream)) return r;
+    BF_HIP(hipMemcpyAsync(c->d_in, c->h_in, m * kCompact, hipMemcpyHostToDevice, c->stream));
+    BF_HIP(bf::launch_mailbox_from_structs(c->d_in, kCompact, m, c->d_mailbox, c->stream));
+    BF_HIP(launch_eval(c, c->d_mailbox, m, c->d_scores, nullptr, c->stream));
+    if (int r = scratch_release(c, c->stream)) return r;
+    BF_HIP(hipMemcpyAsync(c->h_scores, c->d_scores, m * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    return BF_OK;
+}
+
+int finish_shard(bf_ctx* c, size_t n, float* h_scores, bool wire) {
+    DeviceGuard guard(c->device);
+    if (wire) {
+        if (int r = read_err_flag(c, c->stream)) return r;
+    } else {
+        BF_HIP(hipStreamSynchronize(c->stream));
+    }
+    std::memcpy(h_scores, c->h_scores, n * sizeof(float));
+    return BF_OK;
+}
+
+}  // namespace
+
+extern "C" int bf_multi_eval_wire_host(bf_multi* m, const uint8_t* h_pf, size_t n_bytes, const uint64_t* h_occ, size_t n,
+                                       float* h_scores) {
+    if (!m) return bf::fail(BF_E_ARG, "bf_multi_eval_wire_host: null handle");
+    if (int r = check_common(m->ctx[0], n, "bf_multi_eval_wire_host")) return r;
+    if (n == 0) return BF_OK;
+    if (!h_occ || !h_scores || (!h_pf && n_bytes)) return bf::fail(BF_E_ARG, "bf_multi_eval_wire_host: null pointer");
+    std::lock_guard<std::mutex> lock(m->mu);
+    const size_t parts = parts_for(m, n);
+    m->board_lo.assign(parts + 1, 0);
+    m->nibble_lo.assign(parts + 1, 0);
+    if (int r = bf_host_split_wire(h_occ, n, parts, m->board_lo.data(), m->nibble_lo.data())) return r;
+    const size_t total = m->nibble_lo[parts];
+    if ((total + 1) / 2 != n_bytes)
+        return bf::fail(BF_E_FORMAT, "bf_multi_eval_wire_host: %zu piece_filters bytes, but the masks select %zu codes (%zu bytes)",
+                        n_bytes, total, (total + 1) / 2);
+    // all shards are enqueued before any is waited for: the devices run side by side
+    int rc = BF_OK;
+    size_t started = 0;
+    for (; started < parts && rc == BF_OK; ++started) {
+        bf_ctx* c = m->ctx[started];
+        c->mu.lock();
+        const size_t s_lo = m->nibble_lo[started], s_hi = m->nibble_lo[started + 1];
+        const size_t byte_lo = s_lo >> 1, byte_hi = (s_hi + 1) >> 1;
+        rc = start_wire_shard(c, h_pf + byte_lo, byte_hi - byte_lo, (unsigned)(s_lo & 1), h_occ + m->board_lo[started],
+                              m->board_lo[started + 1] - m->board_lo[started]);
+    }
+    for (size_t p = 0; p < started; ++p) {
+        bf_ctx* c = m->ctx[p];
+        // a shard that failed to start may have enqueued part of its work: drain it either way
+        const int r = finish_shard(c, rc == BF_OK ? m->board_lo[p + 1] - m->board_lo[p] : 0, h_scores + m->board_lo[p], true);
+        if (rc == BF_OK) rc = r;
+        c->mu.unlock();
+    }
+    return rc;
+}
+
+extern "C" int bf_multi_eval_structs_host(bf_multi* m, const void* h_structs, size_t stride, const uint8_t* h_mask, size_t n,
+                                          float* h_scores, size_t* n_scored) {
+    if (n_scored) *n_scored = 0;
+    if (!m) return bf::fail(BF_E_ARG, "bf_multi_eval_structs_host: null handle");
+    if (int r = check_common(m->ctx[0], n, "bf_multi_eval_structs_host")) return r;
+    if (n == 0) return BF_OK;
+    if (!h_structs || !h_scores) return bf::fail(BF_E_ARG, "bf_multi_eval_structs_host: null pointer");
+    if (stride < BF_NODE_EVAL_BYTES) return bf::fail(BF_E_ARG, "bf_multi_eval_structs_host: stride %zu < 82", stride);
+    std::lock_guard<std::mutex> lock(m->mu);
+    // gather the selected records once (88-byte stride), then hand contiguous runs to the devices
+    constexpr size_t kCompact = 88;
+    size_t count = 0;
+    if (h_mask) {
+        for (size_t j = 0; j < n; ++j) count += h_mask[j] ? 1 : 0;
+    } else {
+        count = n;
+    }
+    if (count == 0) return BF_OK;
+    std::vector<unsigned char> compact(count * kCompact);
+    const unsigned char* recs = static_cast<const unsigned char*>(h_structs);
+    size_t k = 0;
+    for (size_t j = 0; j < n; ++j) {
+        if (h_mask && !h_mask[j]) continue;
+        std::memcpy(compact.data() + k * kCompact, recs + j * stride, BF_NODE_EVAL_BYTES);
+        ++k;
+    }
+    const size_t parts = parts_for(m, count);
+    int rc = BF_OK;
+    size_t started = 0;
+    auto lo_of = [&](size_t p) { return p * (count / parts) + (p < count % parts ? p : count % parts); };
+    for (; started < parts && rc == BF_OK; ++started) {
+        bf_ctx* c = m->ctx[started];
+        c->mu.lock();
+        rc = start_struct_shard(c, compact.data() + lo_of(started) * kCompact, lo_of(started + 1) - lo_of(started));
+    }
+    for (size_t p = 0; p < started; ++p) {
+        bf_ctx* c = m->ctx[p];
+        const int r = finish_shard(c, rc == BF_OK ? lo_of(p + 1) - lo_of(p) : 0, h_scores + lo_of(p), false);
+        if (rc == BF_OK) rc = r;
+        c->mu.unlock();
+    }
+    if (rc == BF_OK && n_scored) *n_scored = count;
+    return rc;
 }
 
 // ---- the move-scoring network ---------------------------------------------------------------
@@ -457,9 +658,10 @@ extern "C" int bf_policy_features_wire(bf_ctx* c, const uint8_t* d_pf, size_t n_
     DeviceGuard guard(c->device);
     std::lock_guard<std::mutex> lock(c->policy.mu);
     if (int r = ensure_boards(&c->policy, n)) return r;
+    if (int r = scratch_acquire(&c->policy, (hipStream_t)stream)) return r;
     BF_HIP(bf::launch_mailbox_from_wire(d_pf, n_bytes, d_occ, n, workspace(&c->policy), c->policy.d_mailbox, (hipStream_t)stream));
     BF_HIP(launch_policy_features(c, c->policy.d_mailbox, n, d_x9, (hipStream_t)stream));
-    return BF_OK;
+    return scratch_release(&c->policy, (hipStream_t)stream);
 }
 
 extern "C" int bf_policy_features_structs(bf_ctx* c, const void* d_structs, size_t stride, size_t n, float* d_x9,
@@ -471,9 +673,10 @@ extern "C" int bf_policy_features_structs(bf_ctx* c, const void* d_structs, size
     DeviceGuard guard(c->device);
     std::lock_guard<std::mutex> lock(c->policy.mu);
     if (int r = ensure_boards(&c->policy, n)) return r;
+    if (int r = scratch_acquire(&c->policy, (hipStream_t)stream)) return r;
     BF_HIP(bf::launch_mailbox_from_structs(d_structs, stride, n, c->policy.d_mailbox, (hipStream_t)stream));
     BF_HIP(launch_policy_features(c, c->policy.d_mailbox, n, d_x9, (hipStream_t)stream));
-    return BF_OK;
+    return scratch_release(&c->policy, (hipStream_t)stream);
 }
 
 extern "C" int bf_policy_scores(bf_ctx* c, const float* d_x9, size_t n_boards, const uint32_t* d_board_index,
@@ -518,10 +721,12 @@ extern "C" int bf_policy_start_wire_host(bf_ctx* c, const uint8_t* h_pf, size_t 
         if (int r = ensure_staging(L, pf_off + n_bytes + 16, 1)) return r;
         std::memcpy(L->h_in, h_occ, occ_bytes);
         if (n_bytes) std::memcpy(L->h_in + pf_off, h_pf, n_bytes);
+        if (int r = scratch_acquire(L, L->stream)) return r;
         BF_HIP(hipMemcpyAsync(L->d_in, L->h_in, pf_off + n_bytes, hipMemcpyHostToDevice, L->stream));
         BF_HIP(bf::launch_mailbox_from_wire(L->d_in + pf_off, n_bytes, reinterpret_cast<const uint64_t*>(L->d_in), n,
                                             workspace(L), L->d_mailbox, L->stream));
         BF_HIP(launch_policy_features(c, L->d_mailbox, n, c->d_x9, L->stream));
+        if (int r = scratch_release(L, L->stream)) return r;
     }
     c->policy_boards = n;
     c->policy_started = true;
@@ -555,9 +760,11 @@ extern "C" int bf_policy_start_structs_host(bf_ctx* c, const void* h_structs, si
             std::memcpy(L->h_in + k * kCompact, recs + j * stride, BF_NODE_EVAL_BYTES);
             ++k;
         }
+        if (int r = scratch_acquire(L, L->stream)) return r;
         BF_HIP(hipMemcpyAsync(L->d_in, L->h_in, m * kCompact, hipMemcpyHostToDevice, L->stream));
         BF_HIP(bf::launch_mailbox_from_structs(L->d_in, kCompact, m, L->d_mailbox, L->stream));
         BF_HIP(launch_policy_features(c, L->d_mailbox, m, c->d_x9, L->stream));
+        if (int r = scratch_release(L, L->stream)) return r;
     }
     c->policy_boards = m;
     c->policy_started = true;

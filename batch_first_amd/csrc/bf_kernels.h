@@ -16,8 +16,10 @@ struct Workspace {
 
 size_t scan_blocks_for(size_t n);
 
+// start_nibble = 1: the boards are a shard of a longer stream and their first code is the LOW nibble of d_nib[0]
 hipError_t launch_mailbox_from_wire(const uint8_t* d_nib, size_t n_bytes, const uint64_t* d_occ, size_t n,
-                                    const Workspace& ws, uint8_t* d_mailbox, hipStream_t stream);
+                                    const Workspace& ws, uint8_t* d_mailbox, hipStream_t stream,
+                                    unsigned start_nibble = 0);
 hipError_t launch_mailbox_from_structs(const void* d_structs, size_t stride, size_t n, uint8_t* d_mailbox,
                                        hipStream_t stream);
 hipError_t launch_planes_from_wire(const uint8_t* d_nib, size_t n_bytes, const uint64_t* d_occ, size_t n,

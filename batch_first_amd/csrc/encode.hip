@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256) void k_popcount_scan(const uint64_t* __restric
 // Level 2: one block turns block totals into exclusive block bases and validates the stream
 // length (own_concat pads an odd count with one nibble: numba_negamax_zero_window.py:58,65-66).
 __global__ __launch_bounds__(1024) void k_scan_block_totals(unsigned* __restrict__ block_total, unsigned n_blocks,
-                                                             unsigned long long n_bytes, int* __restrict__ err_flag) {
+                                                             unsigned long long n_bytes, unsigned start_nibble,
+                                                             int* __restrict__ err_flag) {
     __shared__ unsigned wave_sum[16];
     __shared__ unsigned carry_s;
     const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -75,7 +76,8 @@ __global__ __launch_bounds__(1024) void k_scan_block_totals(unsigned* __restrict
         __syncthreads();
     }
     if (tid == 0) {
-        const unsigned long long total = carry_s;
+        // a shard of a longer stream may begin on the low nibble of its first byte (start_nibble = 1)
+        const unsigned long long total = (unsigned long long)carry_s + start_nibble;
         if ((total + 1) / 2 != n_bytes) atomicOr(err_flag, 1);
     }
 }
@@ -89,12 +91,14 @@ struct WireSrc {
     const unsigned* local_off;
     const unsigned* block_base;
     int* err_flag;
+    unsigned start_nibble;   // 0, or 1 when the boards are a shard that begins mid-byte
     // ann_creation_helper.py:55-79: the k-th set bit of the mask takes stream nibble off+k
     __device__ __forceinline__ int code(unsigned b, int s) const {
         const uint64_t m = occ[b];
         if (!((m >> s) & 1ull)) return 15;
         const unsigned long long nibble =
-            (unsigned long long)local_off[b] + block_base[b / kScanBoardsPerBlock] + __popcll(m & ((1ull << s) - 1ull));
+            (unsigned long long)start_nibble + local_off[b] + block_base[b / kScanBoardsPerBlock] +
+            __popcll(m & ((1ull << s) - 1ull));
         const unsigned long long byte = nibble >> 1;
         if (byte >= n_bytes) {  // never read past the stream; the length check reports it
             atomicOr(err_flag, 1);
@@ -167,11 +171,12 @@ __global__ __launch_bounds__(256) void k_to_planes(Src src, unsigned n, float* _
 
 inline unsigned blocks_for(size_t n, unsigned per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 
-hipError_t scan_offsets(const uint64_t* d_occ, size_t n, size_t n_bytes, const Workspace& ws, hipStream_t stream) {
+hipError_t scan_offsets(const uint64_t* d_occ, size_t n, size_t n_bytes, unsigned start_nibble, const Workspace& ws,
+                        hipStream_t stream) {
     const unsigned nb = blocks_for(n, kScanBoardsPerBlock);
     hipLaunchKernelGGL(k_popcount_scan, dim3(nb), dim3(256), 0, stream, d_occ, (unsigned)n, ws.local_off, ws.block_total);
     hipLaunchKernelGGL(k_scan_block_totals, dim3(1), dim3(1024), 0, stream, ws.block_total, nb,
-                       (unsigned long long)n_bytes, ws.err_flag);
+                       (unsigned long long)n_bytes, start_nibble, ws.err_flag);
     return hipGetLastError();
 }
 
@@ -180,11 +185,11 @@ hipError_t scan_offsets(const uint64_t* d_occ, size_t n, size_t n_bytes, const W
 size_t scan_blocks_for(size_t n) { return (n + kScanBoardsPerBlock - 1) / kScanBoardsPerBlock; }
 
 hipError_t launch_mailbox_from_wire(const uint8_t* d_nib, size_t n_bytes, const uint64_t* d_occ, size_t n,
-                                    const Workspace& ws, uint8_t* d_mailbox, hipStream_t stream) {
+                                    const Workspace& ws, uint8_t* d_mailbox, hipStream_t stream, unsigned start_nibble) {
     if (n == 0) return hipSuccess;
-    hipError_t e = scan_offsets(d_occ, n, n_bytes, ws, stream);
+    hipError_t e = scan_offsets(d_occ, n, n_bytes, start_nibble, ws, stream);
     if (e != hipSuccess) return e;
-    WireSrc src{d_nib, (unsigned long long)n_bytes, d_occ, ws.local_off, ws.block_total, ws.err_flag};
+    WireSrc src{d_nib, (unsigned long long)n_bytes, d_occ, ws.local_off, ws.block_total, ws.err_flag, start_nibble};
     hipLaunchKernelGGL(k_to_mailbox<WireSrc>, dim3(blocks_for(n, 4)), dim3(256), 0, stream, src, (unsigned)n, d_mailbox);
     return hipGetLastError();
 }
@@ -200,9 +205,9 @@ hipError_t launch_mailbox_from_structs(const void* d_structs, size_t stride, siz
 hipError_t launch_planes_from_wire(const uint8_t* d_nib, size_t n_bytes, const uint64_t* d_occ, size_t n,
                                    const Workspace& ws, float* d_planes, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    hipError_t e = scan_offsets(d_occ, n, n_bytes, ws, stream);
+    hipError_t e = scan_offsets(d_occ, n, n_bytes, 0u, ws, stream);
     if (e != hipSuccess) return e;
-    WireSrc src{d_nib, (unsigned long long)n_bytes, d_occ, ws.local_off, ws.block_total, ws.err_flag};
+    WireSrc src{d_nib, (unsigned long long)n_bytes, d_occ, ws.local_off, ws.block_total, ws.err_flag, 0u};
     hipLaunchKernelGGL(k_to_planes<WireSrc>, dim3(blocks_for(n, 4)), dim3(256), 0, stream, src, (unsigned)n, d_planes);
     return hipGetLastError();
 }

@@ -94,3 +94,23 @@ extern "C" int bf_host_encode_wire(const void* h_structs, size_t stride, const u
     if (n_scored) *n_scored = boards;
     return BF_OK;
 }
+
+// Contiguous shards of a wire-format batch: boards [board_lo[p], board_lo[p+1]) go to
+// part p, sizes differing by at most one (batch_first_amd/distributed.py:shard_range); nibble_lo[p] is
+// the index of the shard's first code in the stream, i.e. the sum of the popcounts in front of it.  A
+// shard whose nibble_lo is odd starts on the LOW nibble of byte nibble_lo / 2.  Both arrays have
+// n_parts + 1 entries; the last ones are n and the total number of codes.
+extern "C" int bf_host_split_wire(const uint64_t* h_occ, size_t n, size_t n_parts, size_t* board_lo, size_t* nibble_lo) {
+    if (!h_occ || !board_lo || !nibble_lo || n_parts == 0) return bf::fail(BF_E_ARG, "bf_host_split_wire: bad argument");
+    const size_t base = n / n_parts, extra = n % n_parts;
+    size_t b = 0, nib = 0;
+    for (size_t p = 0; p < n_parts; ++p) {
+        board_lo[p] = b;
+        nibble_lo[p] = nib;
+        const size_t hi = b + base + (p < extra ? 1 : 0);
+        for (; b < hi; ++b) nib += (size_t)__builtin_popcountll(h_occ[b]);
+    }
+    board_lo[n_parts] = b;
+    nibble_lo[n_parts] = nib;
+    return BF_OK;
+}

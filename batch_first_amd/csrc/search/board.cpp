@@ -282,6 +282,80 @@ bool is_legal(const Board& b, Move m) {
     return false;
 }
 
+// Legality of one move decided from the move itself, without the generator: geometry of the piece
+// on the from-square by walking squares (no attack tables), castling and en-passant conditions
+// spelled out, then the move is made on a copy and the mover's king must not be attacked.  The
+// counterpart of the reference's is_legal_move = is_pseudo_legal_move and not is_into_check
+// (numba_board.py:1109-1151); the sweep of code_testing.py:266-293 holds it against legal_moves().
+bool is_legal_direct(const Board& b, Move m) {
+    if (m.from > 63 || m.to > 63 || m.from == m.to) return false;
+    const int us = b.turn, them = us ^ 1;
+    const u64 own = b.occ_co[us], opp = b.occ_co[them];
+    if (!(own & bit(m.from)) || (own & bit(m.to))) return false;
+    const int pt = piece_type_at(b, m.from);
+    const int fr = m.from >> 3, ff = m.from & 7, tr = m.to >> 3, tf = m.to & 7;
+    const int dr = tr - fr, df = tf - ff, adr = dr < 0 ? -dr : dr, adf = df < 0 ? -df : df;
+    auto path_clear = [&]() {   // squares strictly between from and to on a rank, file or diagonal
+        const int sr = (dr > 0) - (dr < 0), sf = (df > 0) - (df < 0);
+        for (int r = fr + sr, f = ff + sf; r != tr || f != tf; r += sr, f += sf)
+            if (b.occ & bit(r * 8 + f)) return false;
+        return true;
+    };
+    if (m.promo && (pt != PAWN || m.promo < KNIGHT || m.promo > QUEEN)) return false;
+    bool castle = false;
+    switch (pt) {
+        case PAWN: {
+            const int step = us ? 1 : -1, last = us ? 7 : 0, home = us ? 1 : 6;
+            if ((tr == last) != (m.promo != 0)) return false;
+            if (df == 0) {
+                if (b.occ & bit(m.to)) return false;
+                if (dr == step) break;
+                if (dr == 2 * step && fr == home && !(b.occ & bit((fr + step) * 8 + ff))) break;
+                return false;
+            }
+            if (adf != 1 || dr != step) return false;
+            if (opp & bit(m.to)) break;
+            // en passant: onto the empty ep square, with the pawn that just made its double step behind it
+            if (b.ep && m.to == b.ep && tr == (us ? 5 : 2) && !(b.occ & bit(m.to)) &&
+                (b.pawns & opp & bit((tr - step) * 8 + tf)))
+                break;
+            return false;
+        }
+        case KNIGHT:
+            if (!((adr == 1 && adf == 2) || (adr == 2 && adf == 1))) return false;
+            break;
+        case BISHOP:
+            if (adr != adf || !path_clear()) return false;
+            break;
+        case ROOK:
+            if ((dr != 0 && df != 0) || !path_clear()) return false;
+            break;
+        case QUEEN:
+            if (!((adr == adf) || dr == 0 || df == 0) || !path_clear()) return false;
+            break;
+        default:  // king
+            if (adr <= 1 && adf <= 1) break;
+            if (dr != 0 || adf != 2 || m.from != (us ? 4 : 60)) return false;
+            castle = true;
+            break;
+    }
+    if (castle) {
+        const int rook_sq = df > 0 ? m.from + 3 : m.from - 4;
+        if (!(b.castling & bit(rook_sq)) || !(b.rooks & own & bit(rook_sq))) return false;
+        const int lo = rook_sq < m.from ? rook_sq : m.from, hi = rook_sq < m.from ? m.from : rook_sq;
+        for (int s = lo + 1; s < hi; ++s)
+            if (b.occ & bit(s)) return false;
+        const int stepf = df > 0 ? 1 : -1;
+        for (int s = m.from; s != m.to + stepf; s += stepf)   // start, crossed and target square
+            if (attackers(b, them, s, b.occ)) return false;
+        return true;
+    }
+    Board c = b;
+    push(c, m);
+    const u64 k = c.kings & c.occ_co[us];
+    return !k || attackers(c, them, lsb(k), c.occ) == 0;
+}
+
 void push(Board& b, Move m) {
     const int us = b.turn, them = us ^ 1;
     b.hash ^= ep_key(b);

@@ -73,6 +73,7 @@ bool in_check(const Board& b);
 int legal_moves(const Board& b, Move* out);
 bool has_legal_move(const Board& b);
 bool is_legal(const Board& b, Move m);
+bool is_legal_direct(const Board& b, Move m);  // decided from the move alone (no generator); must agree with is_legal
 void push(Board& b, Move m);
 bool insufficient_material(const Board& b);
 void to_whites_perspective(Board& b);

@@ -637,6 +637,53 @@ extern "C" int bfs_push(const char* fen, const uint8_t* move, char* fen_out, siz
     return 0;
 }
 
+extern "C" int bfs_is_legal(const char* fen, const uint8_t* moves, size_t n, uint8_t* by_generator, uint8_t* direct) {
+    Board b;
+    if (!fen || !moves || !by_generator || !direct || !board_from_fen(fen, &b)) return fail("bfs_is_legal: bad argument");
+    for (size_t i = 0; i < n; ++i) {
+        const Move m{moves[3 * i], moves[3 * i + 1], moves[3 * i + 2]};
+        by_generator[i] = is_legal(b, m) ? 1 : 0;
+        direct[i] = is_legal_direct(b, m) ? 1 : 0;
+    }
+    return 0;
+}
+
+extern "C" int bfs_push_record(const void* record, const uint8_t* move, void* record88_out) {
+    if (!record || !move || !record88_out) return fail("bfs_push_record: null pointer");
+    init_tables();
+    EvalRecord r;
+    std::memcpy(&r, record, 82);
+    Board b;
+    from_record(r, &b);
+    const Move m{move[0], move[1], move[2]};
+    if (!is_legal(b, m)) return fail("bfs_push_record: illegal move %u %u %u", move[0], move[1], move[2]);
+    push(b, m);
+    to_record(b, static_cast<EvalRecord*>(record88_out));
+    return 0;
+}
+
+extern "C" int bfs_hash_walk(const char* fen, int lines, int plies, uint64_t seed, uint64_t* positions_checked,
+                             uint64_t* mismatches) {
+    Board start;
+    if (!fen || !positions_checked || !mismatches || !board_from_fen(fen, &start)) return fail("bfs_hash_walk: bad argument");
+    u64 x = seed * 0x9E3779B97F4A7C15ull + 1, checked = 0, bad = 0;
+    for (int l = 0; l < lines; ++l) {
+        Board b = start;
+        for (int p = 0; p < plies; ++p) {
+            Move mv[kMaxMoves];
+            const int k = legal_moves(b, mv);
+            if (!k) break;
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            push(b, mv[x % (u64)k]);   // the hash travels with the board, updated move by move
+            ++checked;
+            if (b.hash != compute_hash(b)) ++bad;
+        }
+    }
+    *positions_checked = checked;
+    *mismatches = bad;
+    return 0;
+}
+
 extern "C" int bfs_record_from_fen(const char* fen, void* record88) {
     Board b;
     if (!fen || !record88 || !board_from_fen(fen, &b)) return fail("bfs_record_from_fen: bad argument");

@@ -66,6 +66,15 @@ int bfs_perft(const char* fen, int depth, uint64_t* nodes);
 int bfs_legal_moves(const char* fen, uint8_t* moves /* [100][3] */, int* n_moves);
 int bfs_legal_moves_record(const void* record82, uint8_t* moves /* [100][3] */, int* n_moves);
 int bfs_push(const char* fen, const uint8_t* move /* [3] */, char* fen_out, size_t cap);
+// is_legal_move on arbitrary (from, to, promotion) triples, decided two ways: *by_generator = the move is
+// among the generated legal moves (what the search uses to vet a table move), *direct = decided from the
+// move alone (numba_board.py:1149-1151).  The reference's sweep: code_testing.py:55-59, :266-293.
+int bfs_is_legal(const char* fen, const uint8_t* moves /* [n][3] */, size_t n, uint8_t* by_generator, uint8_t* direct);
+// child record of a node record after a legal move (push_moves on one record, numba_board.py:242-417)
+int bfs_push_record(const void* record82, const uint8_t* move /* [3] */, void* record88_out);
+// zobrist_hash_test, code_testing.py:86-136: random legal lines of at most `plies` moves from `fen`; at every
+// ply the incrementally maintained hash is compared with the hash computed from scratch.
+int bfs_hash_walk(const char* fen, int lines, int plies, uint64_t seed, uint64_t* positions_checked, uint64_t* mismatches);
 int bfs_record_from_fen(const char* fen, void* record88);
 int bfs_random_playout_records(const char* fen, int plies, uint64_t seed, void* records88, int* n_records);
 

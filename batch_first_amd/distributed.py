@@ -19,6 +19,28 @@ def shard_range(n, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def shard_wire(piece_filters, occupied_bbs, rank, world):
+    """This rank's contiguous shard of a wire-format batch as a stand-alone wire-format pair.
+
+    The nibble stream is cut at sum-of-popcount boundaries; a shard that begins on
+    an odd nibble is shifted by four bits so that its first code sits in a high nibble again, and a
+    shard with an odd number of codes gets the trailing zero nibble own_concat would have given it
+    (numba_negamax_zero_window.py:58,65-66).  (The one-process multi-GPU callable does not re-pack:
+    its decode kernel takes the start nibble, bf_multi_eval_wire_host.)"""
+    pf = np.ascontiguousarray(piece_filters, np.uint8)
+    occ = np.ascontiguousarray(occupied_bbs).view(np.uint64)
+    lo, hi = shard_range(occ.size, rank, world)
+    counts = np.array([bin(int(m)).count("1") for m in occ], dtype=np.int64)
+    s_lo, s_hi = int(counts[:lo].sum()), int(counts[:hi].sum())
+    nibbles = np.empty(2 * pf.size, np.uint8)
+    nibbles[0::2] = pf >> 4
+    nibbles[1::2] = pf & 15
+    mine = nibbles[s_lo:s_hi]
+    if mine.size % 2:
+        mine = np.r_[mine, np.uint8(0)]
+    return ((mine[0::2] << 4) | mine[1::2]).astype(np.uint8), occ[lo:hi].copy()
+
+
 def gather_scores(local_scores, n_total, dst=0, group=None):
     """Gather every rank's shard of scores to ``dst`` in shard order.
 

@@ -67,19 +67,29 @@ def _ctx(handle):
         raise ValueError("unknown batchfirst context handle %r" % (handle,))
 
 
-def _dev(t, dtype, name):
+def _dev(t, dtype, name, c=None):
     if not t.is_cuda:
         raise ValueError("%s must be a device tensor" % name)
     if t.dtype != dtype:
         raise ValueError("%s must have dtype %s" % (name, dtype))
+    if c is not None and t.device != c.device:
+        # the kernels run on the context's GPU: a pointer and a stream from another one must not reach them
+        raise ValueError("%s is on %s, but the context lives on %s" % (name, t.device, c.device))
     return t.contiguous()
+
+
+def _records(t, c):
+    recs = _dev(t, torch.uint8, "records", c)
+    if recs.dim() != 2 or recs.shape[1] < 82:
+        raise ValueError("records must be uint8[N, stride] with stride >= 82")
+    return recs
 
 
 @torch.library.custom_op("batchfirst::eval_wire", mutates_args=())
 def eval_wire(ctx: int, piece_filters: torch.Tensor, occupied_bbs: torch.Tensor) -> torch.Tensor:
     c = _ctx(ctx)
-    pf = _dev(piece_filters, torch.uint8, "piece_filters")
-    occ = _dev(occupied_bbs, torch.int64, "occupied_bbs")
+    pf = _dev(piece_filters, torch.uint8, "piece_filters", c)
+    occ = _dev(occupied_bbs, torch.int64, "occupied_bbs", c)
     out = torch.empty(occ.numel(), dtype=torch.float32, device=occ.device)
     _lib.check(c._lib.bf_eval_wire(c._ctx, pf.data_ptr(), pf.numel(), occ.data_ptr(), occ.numel(), out.data_ptr(),
                                    _stream(occ.device)))
@@ -89,9 +99,7 @@ def eval_wire(ctx: int, piece_filters: torch.Tensor, occupied_bbs: torch.Tensor)
 @torch.library.custom_op("batchfirst::eval_structs", mutates_args=())
 def eval_structs(ctx: int, records: torch.Tensor) -> torch.Tensor:
     c = _ctx(ctx)
-    recs = _dev(records, torch.uint8, "records")
-    if recs.dim() != 2:
-        raise ValueError("records must be uint8[N, stride]")
+    recs = _records(records, c)
     out = torch.empty(recs.shape[0], dtype=torch.float32, device=recs.device)
     _lib.check(c._lib.bf_eval_structs(c._ctx, recs.data_ptr(), recs.shape[1], recs.shape[0], out.data_ptr(),
                                       _stream(recs.device)))
@@ -101,7 +109,7 @@ def eval_structs(ctx: int, records: torch.Tensor) -> torch.Tensor:
 @torch.library.custom_op("batchfirst::eval_mailbox", mutates_args=())
 def eval_mailbox(ctx: int, mailbox: torch.Tensor) -> torch.Tensor:
     c = _ctx(ctx)
-    mb = _dev(mailbox, torch.uint8, "mailbox")
+    mb = _dev(mailbox, torch.uint8, "mailbox", c)
     if mb.dim() != 2 or mb.shape[1] != 32:
         raise ValueError("mailbox must be uint8[N, 32]")
     out = torch.empty(mb.shape[0], dtype=torch.float32, device=mb.device)
@@ -112,8 +120,8 @@ def eval_mailbox(ctx: int, mailbox: torch.Tensor) -> torch.Tensor:
 @torch.library.custom_op("batchfirst::encode_planes_wire", mutates_args=())
 def encode_planes_wire(ctx: int, piece_filters: torch.Tensor, occupied_bbs: torch.Tensor) -> torch.Tensor:
     c = _ctx(ctx)
-    pf = _dev(piece_filters, torch.uint8, "piece_filters")
-    occ = _dev(occupied_bbs, torch.int64, "occupied_bbs")
+    pf = _dev(piece_filters, torch.uint8, "piece_filters", c)
+    occ = _dev(occupied_bbs, torch.int64, "occupied_bbs", c)
     out = torch.empty((occ.numel(), 15, 8, 8), dtype=torch.float32, device=occ.device)
     _lib.check(c._lib.bf_encode_planes_wire(c._ctx, pf.data_ptr(), pf.numel(), occ.data_ptr(), occ.numel(),
                                             out.data_ptr(), _stream(occ.device)))
@@ -123,9 +131,7 @@ def encode_planes_wire(ctx: int, piece_filters: torch.Tensor, occupied_bbs: torc
 @torch.library.custom_op("batchfirst::encode_planes_structs", mutates_args=())
 def encode_planes_structs(ctx: int, records: torch.Tensor) -> torch.Tensor:
     c = _ctx(ctx)
-    recs = _dev(records, torch.uint8, "records")
-    if recs.dim() != 2:
-        raise ValueError("records must be uint8[N, stride]")
+    recs = _records(records, c)
     out = torch.empty((recs.shape[0], 15, 8, 8), dtype=torch.float32, device=recs.device)
     _lib.check(c._lib.bf_encode_planes_structs(c._ctx, recs.data_ptr(), recs.shape[1], recs.shape[0],
                                                out.data_ptr(), _stream(recs.device)))
@@ -135,8 +141,8 @@ def encode_planes_structs(ctx: int, records: torch.Tensor) -> torch.Tensor:
 @torch.library.custom_op("batchfirst::encode_mailbox_wire", mutates_args=())
 def encode_mailbox_wire(ctx: int, piece_filters: torch.Tensor, occupied_bbs: torch.Tensor) -> torch.Tensor:
     c = _ctx(ctx)
-    pf = _dev(piece_filters, torch.uint8, "piece_filters")
-    occ = _dev(occupied_bbs, torch.int64, "occupied_bbs")
+    pf = _dev(piece_filters, torch.uint8, "piece_filters", c)
+    occ = _dev(occupied_bbs, torch.int64, "occupied_bbs", c)
     out = torch.empty((occ.numel(), 32), dtype=torch.uint8, device=occ.device)
     _lib.check(c._lib.bf_encode_mailbox_wire(c._ctx, pf.data_ptr(), pf.numel(), occ.data_ptr(), occ.numel(),
                                              out.data_ptr(), _stream(occ.device)))
@@ -146,9 +152,7 @@ def encode_mailbox_wire(ctx: int, piece_filters: torch.Tensor, occupied_bbs: tor
 @torch.library.custom_op("batchfirst::encode_mailbox_structs", mutates_args=())
 def encode_mailbox_structs(ctx: int, records: torch.Tensor) -> torch.Tensor:
     c = _ctx(ctx)
-    recs = _dev(records, torch.uint8, "records")
-    if recs.dim() != 2:
-        raise ValueError("records must be uint8[N, stride]")
+    recs = _records(records, c)
     out = torch.empty((recs.shape[0], 32), dtype=torch.uint8, device=recs.device)
     _lib.check(c._lib.bf_encode_mailbox_structs(c._ctx, recs.data_ptr(), recs.shape[1], recs.shape[0],
                                                 out.data_ptr(), _stream(recs.device)))
@@ -158,8 +162,8 @@ def encode_mailbox_structs(ctx: int, records: torch.Tensor) -> torch.Tensor:
 @torch.library.custom_op("batchfirst::policy_features_wire", mutates_args=())
 def policy_features_wire(ctx: int, piece_filters: torch.Tensor, occupied_bbs: torch.Tensor) -> torch.Tensor:
     c = _ctx(ctx)
-    pf = _dev(piece_filters, torch.uint8, "piece_filters")
-    occ = _dev(occupied_bbs, torch.int64, "occupied_bbs")
+    pf = _dev(piece_filters, torch.uint8, "piece_filters", c)
+    occ = _dev(occupied_bbs, torch.int64, "occupied_bbs", c)
     out = torch.empty((occ.numel(), 32, 8, 8), dtype=torch.float32, device=occ.device)
     _lib.check(c._lib.bf_policy_features_wire(c._ctx, pf.data_ptr(), pf.numel(), occ.data_ptr(), occ.numel(),
                                               out.data_ptr(), _stream(occ.device)))
@@ -169,9 +173,7 @@ def policy_features_wire(ctx: int, piece_filters: torch.Tensor, occupied_bbs: to
 @torch.library.custom_op("batchfirst::policy_features_structs", mutates_args=())
 def policy_features_structs(ctx: int, records: torch.Tensor) -> torch.Tensor:
     c = _ctx(ctx)
-    recs = _dev(records, torch.uint8, "records")
-    if recs.dim() != 2:
-        raise ValueError("records must be uint8[N, stride]")
+    recs = _records(records, c)
     out = torch.empty((recs.shape[0], 32, 8, 8), dtype=torch.float32, device=recs.device)
     _lib.check(c._lib.bf_policy_features_structs(c._ctx, recs.data_ptr(), recs.shape[1], recs.shape[0],
                                                  out.data_ptr(), _stream(recs.device)))
@@ -183,10 +185,10 @@ def policy_scores(ctx: int, features: torch.Tensor, from_squares: torch.Tensor, 
                   moves_per_board: torch.Tensor) -> torch.Tensor:
     """Stage 2: one score per move; the three move tensors are uint8 device tensors."""
     c = _ctx(ctx)
-    x9 = _dev(features, torch.float32, "features")
-    frm = _dev(from_squares, torch.uint8, "from_squares")
-    flt = _dev(move_filters, torch.uint8, "move_filters")
-    per = _dev(moves_per_board, torch.uint8, "moves_per_board")
+    x9 = _dev(features, torch.float32, "features", c)
+    frm = _dev(from_squares, torch.uint8, "from_squares", c)
+    flt = _dev(move_filters, torch.uint8, "move_filters", c)
+    per = _dev(moves_per_board, torch.uint8, "moves_per_board", c)
     n = x9.shape[0]
     if per.numel() != n or frm.numel() != flt.numel():
         raise ValueError("moves_per_board needs one entry per board, from_squares and move_filters one per move")
@@ -203,7 +205,7 @@ def policy_scores(ctx: int, features: torch.Tensor, from_squares: torch.Tensor, 
 def eval_mailbox_debug(ctx, mailbox):
     """Scores plus every intermediate activation (testing aid; not a registered op)."""
     c = _ctx(ctx)
-    mb = _dev(mailbox, torch.uint8, "mailbox")
+    mb = _dev(mailbox, torch.uint8, "mailbox", c)
     n = mb.shape[0]
     per = c._lib.bf_debug_floats_per_board()
     scores = torch.empty(n, dtype=torch.float32, device=mb.device)

@@ -56,6 +56,15 @@ def load():
         lib.bfs_legal_moves_record.restype = _c.c_int
         lib.bfs_legal_moves_record.argtypes = [_c.c_void_p, _c.c_void_p, _c.POINTER(_c.c_int)]
         lib.bfs_push.argtypes = [_c.c_char_p, _c.c_void_p, _c.c_char_p, _c.c_size_t]
+        for name in ("bfs_is_legal", "bfs_push_record", "bfs_hash_walk"):
+            getattr(lib, name).restype = _c.c_int
+        lib.bfs_is_legal.argtypes = [_c.c_char_p, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p]
+        lib.bfs_push_record.argtypes = [_c.c_void_p, _c.c_void_p, _c.c_void_p]
+        lib.bfs_hash_walk.argtypes = [_c.c_char_p, _c.c_int, _c.c_int, _c.c_uint64, _c.POINTER(_c.c_uint64),
+                                      _c.POINTER(_c.c_uint64)]
+        lib.bfs_material_eval.restype = _c.c_int
+        lib.bfs_material_eval.argtypes = [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_size_t, _c.c_void_p,
+                                          _c.POINTER(_c.c_size_t)]
         lib.bfs_record_from_fen.argtypes = [_c.c_char_p, _c.c_void_p]
         lib.bfs_random_playout_records.argtypes = [_c.c_char_p, _c.c_int, _c.c_uint64, _c.c_void_p, _c.POINTER(_c.c_int)]
         lib.bfs_negamax.argtypes = [_c.c_char_p, _c.c_int, _c.c_void_p, _c.c_void_p, _c.POINTER(_c.c_float)]
@@ -107,6 +116,31 @@ def push(fen, move):
     out = _c.create_string_buffer(128)
     _check(load().bfs_push(fen.encode(), mv.ctypes.data, out, 128))
     return out.value.decode()
+
+
+def is_legal(fen, moves):
+    """(by_generator, direct): legality of each (from, to, promotion) triple, decided by membership in the
+    generated legal moves and from the move alone (code_testing.py:266-293)."""
+    mv = np.ascontiguousarray(moves, np.uint8).reshape(-1, 3)
+    a, b = np.zeros(len(mv), np.uint8), np.zeros(len(mv), np.uint8)
+    _check(load().bfs_is_legal(fen.encode(), mv.ctypes.data, len(mv), a.ctypes.data, b.ctypes.data))
+    return a.astype(bool), b.astype(bool)
+
+
+def push_record(record, move):
+    """The 88-byte child record of a node record after a legal move."""
+    rec = np.ascontiguousarray(record).view(np.uint8).ravel()
+    mv = np.ascontiguousarray(move, np.uint8)
+    out = np.zeros(88, np.uint8)
+    _check(load().bfs_push_record(rec.ctypes.data, mv.ctypes.data, out.ctypes.data))
+    return out
+
+
+def hash_walk(fen, lines=1000, plies=20, seed=1):
+    """(positions checked, mismatches) of incremental against recomputed hashes (code_testing.py:86-136)."""
+    n, bad = _c.c_uint64(0), _c.c_uint64(0)
+    _check(load().bfs_hash_walk(fen.encode(), int(lines), int(plies), int(seed), _c.byref(n), _c.byref(bad)))
+    return n.value, bad.value
 
 
 def record_from_fen(fen):
@@ -167,7 +201,11 @@ class Search:
         from . import _lib as hip
         lib = hip.load()
         ctx = predictor._handle()
-        args = dict(board_eval=_c.cast(lib.bf_eval_structs_host, _c.c_void_p).value, eval_user=ctx)
+        if hasattr(predictor, "_multi_handle"):   # chestimator.MultiDevicePredictor: same signature, handle as user
+            args = dict(board_eval=_c.cast(lib.bf_multi_eval_structs_host, _c.c_void_p).value,
+                        eval_user=predictor._multi_handle())
+        else:
+            args = dict(board_eval=_c.cast(lib.bf_eval_structs_host, _c.c_void_p).value, eval_user=ctx)
         if use_policy and predictor.has_policy:
             args.update(move_start=_c.cast(lib.bf_policy_start_structs_host, _c.c_void_p).value,
                         move_finish=_c.cast(lib.bf_policy_finish_host, _c.c_void_p).value, move_user=ctx)

@@ -119,9 +119,7 @@ def main():
         n = hi - lo
     else:
         n = args.batch
-    ctx = ops.DeviceContext(weights.make_weights(seed=1234, bn="perturbed"), device=local_rank, dtype=args.dtype)
-    bf16 = args.dtype == "bf16"
-    peak_tflops = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+    w = weights.make_weights(seed=1234, bn="perturbed")
     if shard:
         # 2^24 synthetic boards: a seeded 65536-board block per rank, repeated (the generator is a host loop)
         block = ops.records_to_tensor(positions.to_compact(positions.random_structs(65536, seed=1000 + rank)), dev)
@@ -130,50 +128,89 @@ def main():
         recs = ops.records_to_tensor(positions.to_compact(positions.random_structs(n, seed=1000 + rank)), dev)
     gathered = [torch.empty(n, dtype=torch.float32, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
 
-    def step():
-        scores = torch.ops.batchfirst.eval_structs(ctx.handle, recs)
-        if world > 1:
-            dist.gather(scores, gathered, dst=0)  # RCCL: scores back to the search host's rank
-        return scores
-
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        scores = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert bool(torch.isfinite(scores).all())
+    def measure(dtype):
+        """The timed region of the contract (W warm-up steps, exactly K steps between fences, MAX over
+        ranks) and then the dominant kernel alone, for one precision.  Returns (elapsed seconds of the K
+        steps, kernel ms per 65 536-board launch, the context)."""
+        ctx = ops.DeviceContext(w, device=local_rank, dtype=dtype)
 
-    # dominant kernel alone (k_eval_f32), HIP events on the stream it is launched on
+        def step():
+            scores = torch.ops.batchfirst.eval_structs(ctx.handle, recs)
+            if world > 1:
+                dist.gather(scores, gathered, dst=0)  # RCCL: scores back to the search host's rank
+            return scores
+
+        for _ in range(args.warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            scores = step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        assert bool(torch.isfinite(scores).all())
+        # dominant kernel alone, HIP events on the stream it is launched on, quoted at 65 536 boards
+        krecs = recs[:65536].contiguous() if shard else recs
+        mailbox = torch.ops.batchfirst.encode_mailbox_structs(ctx.handle, krecs)
+        reps = max(3, min(args.steps, 20))
+        # untimed burst first: after the host-side checks above the GPU has idled and its clock ramps up over the
+        # first launches (single launches with a sync between them measure 2-5 % slower than a running burst)
+        for _ in range(reps):
+            torch.ops.batchfirst.eval_mailbox(ctx.handle, mailbox)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(reps):
+            torch.ops.batchfirst.eval_mailbox(ctx.handle, mailbox)
+        ev1.record()
+        torch.cuda.synchronize()
+        return elapsed, ev0.elapsed_time(ev1) / reps, ctx
+
+    bf16 = args.dtype == "bf16"
+    peak_tflops = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+    elapsed, kernel_ms, ctx = measure(args.dtype)
+    total_boards = (1 << 24) if shard else world * n
+    n_kernel = 65536 if shard else n
+    achieved_tflops = spec.FLOPS_PER_BOARD * n_kernel / (kernel_ms * 1e-3) / 1e12
+    # BASELINE configs[2] beside the fp32 headline, in the same run and under the same contract: the bf16
+    # kernel on the same records (the headline fields above stay those of --dtype)
+    other = None
+    if not bf16:
+        o_elapsed, o_kernel_ms, o_ctx = measure("bf16")
+        o_tflops = spec.FLOPS_PER_BOARD * n_kernel / (o_kernel_ms * 1e-3) / 1e12
+        o_traffic, o_src = profiled_traffic("bf16")
+        other = {"value": total_boards * args.steps / o_elapsed, "unit": "boards/s", "steps": args.steps, "warmup": args.warmup,
+                 "ms_per_step": 1e3 * o_elapsed / args.steps, "dtype": "bf16",
+                 "config": {"workload": "BASELINE configs[2] kernel (bf16 operands, fp32 sums) on the headline's records and batch"},
+                 "roofline": {"bound": "mfma", "kernel": "k_eval_bf16", "achieved": o_tflops, "peak": PEAK_BF16_MFMA_TFLOPS,
+                              "unit": "TFLOP/s", "frac": o_tflops / PEAK_BF16_MFMA_TFLOPS, "kernel_ms": o_kernel_ms,
+                              "traffic": o_traffic, "traffic_source": o_src, "flops_per_board": spec.FLOPS_PER_BOARD}}
+        o_ctx.close()
     if shard:
-        recs = recs[:65536].contiguous()   # the kernel-alone figures below are quoted at 65536 boards
+        recs = recs[:65536].contiguous()
         n = 65536
-    mailbox = torch.ops.batchfirst.encode_mailbox_structs(ctx.handle, recs)
     reps = max(3, min(args.steps, 20))
-    # untimed burst first: after the host-side checks above the GPU has idled and its clock ramps up over the
-    # first launches (single launches with a sync between them measure 2-5 % slower than a running burst)
-    for _ in range(reps):
-        torch.ops.batchfirst.eval_mailbox(ctx.handle, mailbox)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    ev0.record()
-    for _ in range(reps):
-        torch.ops.batchfirst.eval_mailbox(ctx.handle, mailbox)
-    ev1.record()
-    torch.cuda.synchronize()
-    kernel_ms = ev0.elapsed_time(ev1) / reps
-    achieved_tflops = spec.FLOPS_PER_BOARD * n / (kernel_ms * 1e-3) / 1e12
+
+    # who ran: what torch.distributed and every rank's device report (a SCALE run shows its ranks here)
+    prop = torch.cuda.get_device_properties(dev)
+    me = {"rank": rank, "local_rank": local_rank, "device_index": dev.index, "name": prop.name,
+          "gcnArchName": getattr(prop, "gcnArchName", ""), "cus": prop.multi_processor_count}
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
+        dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": ranks}
+    else:
+        dist_info = {"world_size": 1, "backend": None, "ranks": [me]}
 
     # the encoding kernel alone against HBM (records -> float planes, 88 B in + 3840 B out per board)
     # straight through the C ABI into one preallocated output: a 45 us kernel behind a Python custom op
@@ -199,7 +236,7 @@ def main():
 
     traffic, traffic_src = profiled_traffic(args.dtype)
     if rank == 0:
-        value = ((1 << 24) if shard else world * n) * args.steps / elapsed
+        value = total_boards * args.steps / elapsed
         out = {
             "metric": "board evals/sec, 2^24 boards sharded" if shard else "board evals/sec at batch 65536",
             "value": value,
@@ -218,7 +255,7 @@ def main():
                                    "random init, batch %d per GPU, %s, from packed node records resident in HBM "
                                    "(fused ingest + conv + head)" % (n, "bf16 operands / fp32 sums (configs[2] kernel)" if bf16 else "fp32"),
                        "per_gpu_batch": ((1 << 24) // world) if shard else n,
-                       "global_batch": (1 << 24) if shard else world * n,
+                       "global_batch": total_boards,
                        "parallelism": "independent shards per GPU" + (", RCCL gather of scores to rank 0" if world > 1 else "")},
             "roofline": {"bound": "mfma", "kernel": "k_eval_bf16" if bf16 else "k_eval_f32", "achieved": achieved_tflops,
                          "peak": peak_tflops, "unit": "TFLOP/s", "frac": achieved_tflops / peak_tflops,
@@ -229,6 +266,9 @@ def main():
                                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": enc_gbs / PEAK_HBM_GBS,
                                 "kernel_ms": enc_ms, "bytes_per_board": 88 + 3840},
         }
+        out["distributed"] = dist_info
+        if other is not None:
+            out["bf16"] = other
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -9,7 +9,11 @@
  *     the calling thread's last failure.
  *   - "d_" arguments are device pointers on the context's GPU, "h_" arguments host pointers.
  *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).  Device
- *     entry points only enqueue work on it; they never synchronise.
+ *     entry points only enqueue work on it; they never synchronise.  Calls on one context may use
+ *     different streams and threads: entry points that go through the context's scratch (wire
+ *     decode, mailboxes) order themselves behind the previous such call with an event, so a call
+ *     on stream B never overwrites scratch that a call on stream A is still reading (the callers'
+ *     own input and output buffers remain the callers' business).
  *   - Square numbering, bitboards, colours as in batch_first/__init__.py:176-205
  *     (a1 = bit 0, h8 = bit 63, occupied_co[0] = black, [1] = white, turn 1 = white).
  *
@@ -157,6 +161,28 @@ int bf_eval_wire_host(bf_ctx* ctx, const uint8_t* h_piece_filters, size_t n_byte
 int bf_eval_structs_host(bf_ctx* ctx, const void* h_structs, size_t stride, const uint8_t* h_mask,
                          size_t n, float* h_scores, size_t* n_scored);
 
+/* ---- several GPUs behind one call ------------------------------------------------------------
+ *
+ * No counterpart in the reference (every placement there is '/GPU:0', chestimator.py:33).  north_star:
+ * "independent boards on each GPU on separate HIP streams ... gather scores back to the search host".
+ * A bf_multi borrows one context per GPU (same weights and precision in each, which the caller
+ * guarantees by creating them from one blob) and splits every batch into contiguous shards, one per
+ * device: all shards' copies and kernels are enqueued on the contexts' own streams from the calling
+ * thread before any is waited for, so the devices run side by side, and the scores land in one host
+ * array in board order.  The wire format is split at sum-of-popcount boundaries; a shard that begins
+ * on an odd code starts on the low nibble of its first byte, which the decode kernel is told
+ * (no re-packing).  Batches below min_shard boards per device use fewer devices (a search's small
+ * batches stay on one GPU).  Signatures match bf_eval_wire_host / bf_eval_structs_host with the
+ * handle in place of the context, so the search driver takes either. */
+typedef struct bf_multi bf_multi;
+int bf_multi_create(bf_multi** out, bf_ctx* const* ctxs, size_t n_ctx, size_t min_shard);
+void bf_multi_destroy(bf_multi* m);   /* the contexts are the caller's to destroy */
+size_t bf_multi_devices(const bf_multi* m);
+int bf_multi_eval_wire_host(bf_multi* m, const uint8_t* h_piece_filters, size_t n_bytes,
+                            const uint64_t* h_occupied_bbs, size_t n, float* h_scores);
+int bf_multi_eval_structs_host(bf_multi* m, const void* h_structs, size_t stride, const uint8_t* h_mask,
+                               size_t n, float* h_scores, size_t* n_scored);
+
 /* ---- the move-scoring ("policy") network ------------------------------------------------
  *
  * batch_first/anns/move_evaluation_ann.py:10-73: the same nine input convolutions and tower as
@@ -221,6 +247,11 @@ int bf_policy_finish_host(bf_ctx* ctx, const uint8_t* h_from_square, const uint8
 int bf_host_encode_wire(const void* h_structs, size_t stride, const uint8_t* h_mask, size_t n,
                         uint8_t* h_piece_filters, uint64_t* h_occupied_bbs,
                         size_t* n_bytes, size_t* n_scored);
+
+/* How bf_multi_eval_wire_host cuts a wire-format batch into n_parts contiguous shards (host only):
+ * board_lo[p] and nibble_lo[p] (n_parts + 1 entries each) are shard p's first board and the index of
+ * its first code in the stream; an odd nibble_lo means the shard starts on a low nibble. */
+int bf_host_split_wire(const uint64_t* h_occupied_bbs, size_t n, size_t n_parts, size_t* board_lo, size_t* nibble_lo);
 
 /* Size in floats of the fragment-ordered weight image the kernels read, and the image itself
  * (bf_ctx_create uploads exactly this).  Exposed so the arrangement can be checked on a CPU. */

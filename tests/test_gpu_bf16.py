@@ -12,13 +12,18 @@ to bf16, float32 sums).  Bars, stated here as north_star asks:
 * end to end against that model: |g - m| <= 3e-2 * max(|m|, rms(m)) -- a flipped rounding grows
   through the six 3x3 layers, so the model is no tighter a witness than the FP32 oracle here
   (measured: worst 1.7e-2, mean 1e-3);
-* against the FP32 oracle (golden scores): |g - r| <= 5e-2 * max(|r|, rms(r)) (measured: worst
-  2.9e-2, mean 5.8e-3; the CPU model itself sits at the same distance);
-* move ordering: within every sibling group the arg-max is the FP32 arg-max whenever FP32 separates
-  its top two by more than 4x the bf16 tolerance, and every pair of group members that FP32
-  separates by more than that is ordered the same way.  The reference's sibling groups are the
-  children of one parent (numba_negamax_zero_window.py:315-347); no move generator is in scope, so
-  groups here are the 32 consecutive 32-board slices of the 1024-position golden set.
+* against the FP32 oracle (golden scores): |g - r| <= FP32_TOL * max(|r|, rms(r)), FP32_TOL = 4e-2
+  (measured worst: 2.9e-2 on the 1024 golden positions, 3.3e-2 on the 3734 sibling positions, mean
+  6e-3; the CPU model itself sits at the same distance; round 1 allowed 5e-2);
+* move ordering on REAL sibling groups (tests/golden/siblings_128.npz: 128 parents from random legal
+  playouts, every legal move of each, 20-40 children a group -- what create_child_structs,
+  numba_negamax_zero_window.py:315-347, hands the evaluator): the arg-max is the FP32 arg-max
+  whenever FP32 separates its top two by more than ORDER_GAP = 4 x FP32_TOL x rms,
+  and every pair that FP32 separates by more than that keeps its order.  Because both scores of a
+  pair move by at most the tolerance, the same must already hold at HALF that gap, which is asserted
+  too.  Below the gap bf16 does reorder siblings (with random-init weights a group spreads over only
+  0.18 rms; the CPU model flips 1.2 % of all sibling pairs and 4 of the 128 arg-maxima): the test
+  prints those counts, north_star's "identical move ordering" holds above the stated gap only.
 """
 import numpy as np
 import pytest
@@ -29,7 +34,8 @@ from oracle import encoding as E, network as N
 pytestmark = pytest.mark.gpu
 
 MODEL_TOL = 3e-2
-FP32_TOL = 5e-2
+FP32_TOL = 4e-2
+ORDER_GAP = 4 * FP32_TOL      # in units of the fp32 scores' rms
 
 
 def _rel(got, ref):
@@ -128,25 +134,60 @@ def test_bf16_entry_points_agree_and_are_deterministic(ctx16, predictor16, golde
     assert a[3] == a[4]   # mirrored reference FENs (code_testing.py:36-37)
 
 
-def test_bf16_move_ordering(predictor16, golden):
-    got = predictor16(golden["piece_filters"], golden["occupied_bbs"]).astype(np.float64)
-    ref = golden["scores_f32_perturbed"].astype(np.float64)
-    rms = float(np.sqrt(np.mean(ref ** 2)))
-    gap = 4 * FP32_TOL * rms
-    checked_top = checked_pairs = 0
-    for g in range(32):
-        r, s = ref[32 * g:32 * g + 32], got[32 * g:32 * g + 32]
+@pytest.fixture(scope="module")
+def siblings():
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "siblings_128.npz")
+    with np.load(path) as z:
+        return {k: z[k] for k in z.files}
+
+
+def ordering_report(got, ref, group_sizes, gap):
+    """Per sibling group: arg-max and pair order of `got` against `ref` wherever `ref` separates by more
+    than `gap`.  Returns counts; raises on a violation."""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    pos = 0
+    out = dict(groups=0, top_checked=0, pairs_checked=0, pairs=0, flipped_below_gap=0, argmax_moved=0)
+    for k in group_sizes:
+        k = int(k)
+        r, s = ref[pos:pos + k], got[pos:pos + k]
+        pos += k
         order = np.argsort(-r)
         if r[order[0]] - r[order[1]] > gap:
-            assert int(np.argmax(s)) == int(order[0]), g
-            checked_top += 1
-        dr = r[:, None] - r[None, :]
-        ds = s[:, None] - s[None, :]
+            assert int(np.argmax(s)) == int(order[0]), ("arg-max moved", out["groups"])
+            out["top_checked"] += 1
+        out["argmax_moved"] += int(np.argmax(s) != order[0])
+        dr, ds = r[:, None] - r[None, :], s[:, None] - s[None, :]
         sep = dr > gap
-        assert np.all(ds[sep] > 0), g
-        checked_pairs += int(sep.sum())
-    print("ordering: %d group maxima and %d separated pairs checked (gap %.4f)" % (checked_top, checked_pairs, gap))
-    assert checked_pairs > 1000
+        assert np.all(ds[sep] > 0), ("pair reordered above the gap", out["groups"])
+        out["pairs_checked"] += int(sep.sum())
+        iu = np.triu_indices(k, 1)
+        out["pairs"] += len(iu[0])
+        out["flipped_below_gap"] += int(np.sum(np.sign(dr[iu]) != np.sign(ds[iu])))
+        out["groups"] += 1
+    assert pos == len(ref)
+    return out
+
+
+def test_bf16_move_ordering_on_real_sibling_groups(predictor16, siblings):
+    structs = np.frombuffer(siblings["records"].tobytes(), dtype=P.COMPACT_DTYPE)
+    got = predictor16.eval_structs(structs)
+    again = predictor16(siblings["piece_filters"], siblings["occupied_bbs"])
+    assert np.array_equal(got.view(np.uint32), again.view(np.uint32))
+    ref = siblings["scores_f32"]
+    e, rms = _rel(got, ref)
+    print("siblings: worst vs fp32 oracle %.2e, mean %.2e (rms score %.3f)" % (e.max(), e.mean(), rms))
+    assert e.max() <= FP32_TOL
+    sizes = siblings["group_sizes"]
+    assert len(sizes) == 128 and sizes.min() >= 20 and sizes.max() <= 40
+    rep = ordering_report(got, ref, sizes, ORDER_GAP * rms)
+    half = ordering_report(got, ref, sizes, 0.5 * ORDER_GAP * rms)
+    print("ordering above %.3f rms: %d arg-maxima, %d pairs kept; above half the gap: %d arg-maxima, %d pairs kept; "
+          "below: %d of %d pairs and %d of 128 arg-maxima differ from fp32"
+          % (ORDER_GAP, rep["top_checked"], rep["pairs_checked"], half["top_checked"], half["pairs_checked"],
+             rep["flipped_below_gap"], rep["pairs"], rep["argmax_moved"]))
+    assert rep["groups"] == 128 and rep["pairs_checked"] > 10000 and half["pairs_checked"] > rep["pairs_checked"]
+    assert rep["flipped_below_gap"] < 0.03 * rep["pairs"]
 
 
 def test_bf16_batch_65536_properties(ctx16, golden, model_scores):

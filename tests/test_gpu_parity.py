@@ -298,3 +298,85 @@ def test_scores_on_random_legal_positions(predictor):
     ok64, w64 = _score_ok(a, g["scores_f64"])
     print("legal positions: worst error / bound %.3f vs f32 oracle, %.3f vs f64 oracle" % (w32, w64))
     assert ok32 and ok64
+
+
+def test_two_streams_on_one_context_do_not_share_scratch_in_flight(torch_mod, ctx, golden):
+    """Device entry points only enqueue, and calls on one context may come on different streams:
+    the context's mailbox / offset scratch is handed from one call to the next by an event
+    (api.hip, Lane::scratch_done).  A long call on stream A followed at once by a short call on
+    stream B, which rewrites the first mailboxes: both must give the scores of a serial run."""
+    torch = torch_mod
+    big = torch.from_numpy(np.tile(golden["records"], (64, 1))).cuda()                   # 65 536 boards, ~16 ms
+    small = torch.from_numpy(np.ascontiguousarray(golden["records"][::-1][:512])).cuda()  # other boards, same slots
+    pf, occ = _dev_wire(torch, golden)
+    want_big = torch.ops.batchfirst.eval_structs(ctx.handle, big).cpu().numpy()
+    want_small = torch.ops.batchfirst.eval_structs(ctx.handle, small).cpu().numpy()
+    want_wire = torch.ops.batchfirst.eval_wire(ctx.handle, pf, occ).cpu().numpy()
+    torch.cuda.synchronize()
+    sa, sb, sc = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(3):
+        with torch.cuda.stream(sa):
+            got_big = torch.ops.batchfirst.eval_structs(ctx.handle, big)
+        with torch.cuda.stream(sb):
+            got_small = torch.ops.batchfirst.eval_structs(ctx.handle, small)
+        with torch.cuda.stream(sc):
+            got_wire = torch.ops.batchfirst.eval_wire(ctx.handle, pf, occ)
+        torch.cuda.synchronize()
+        assert np.array_equal(got_big.cpu().numpy().view(np.uint32), want_big.view(np.uint32))
+        assert np.array_equal(got_small.cpu().numpy().view(np.uint32), want_small.view(np.uint32))
+        assert np.array_equal(got_wire.cpu().numpy().view(np.uint32), want_wire.view(np.uint32))
+    ctx.check()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_multi_device_callable_equals_single_device(torch_mod, golden, dtype):
+    """get_inference_functions(..., devices=[...]): one callable over every visible GPU (one context and
+    one stream per device, wire format split at popcount boundaries, odd-nibble shard starts handled by
+    the decode kernel).  On a one-GPU box the same code path runs with two contexts on device 0, so the
+    splitting, the start-nibble decode and the gather are exercised either way; scores must be bit-equal
+    to the single-device callable's for every split."""
+    from batch_first_amd import chestimator, search
+    w = W.to_blob(W.make_weights(seed=1234, bn="perturbed"))
+    single, _, close_single = chestimator.get_inference_functions(w, dtype=dtype)
+    count = torch_mod.cuda.device_count()
+    structs = np.frombuffer(golden["records"].tobytes(), dtype=P.COMPACT_DTYPE)
+    counts = np.array([bin(int(m)).count("1") for m in golden["occupied_bbs"]])
+    try:
+        want = single(golden["piece_filters"], golden["occupied_bbs"])
+        if count > 1:
+            multi, _, close_multi = chestimator.get_inference_functions(w, dtype=dtype, devices=list(range(count)), min_shard=64)
+        else:
+            # three contexts (streams) on the one device behind the same handle
+            multi = chestimator.MultiDevicePredictor(w, [0, 0, 0], dtype=dtype, min_shard=64, allow_repeats=True)
+            close_multi = multi.close
+        try:
+            odd = 0
+            for n in (1024, 1023, 777, 500, 193, 130, 64, 5, 1):
+                nib, occ = E.struct_array_to_ann_inputs(structs[:n])
+                got = multi(nib, occ)
+                assert np.array_equal(got.view(np.uint32), want[:n].view(np.uint32)), n
+                got2 = multi.eval_structs(structs[:n])
+                assert np.array_equal(got2.view(np.uint32), want[:n].view(np.uint32)), n
+                parts_n = min(len(multi.parts), max(1, n // 64))
+                odd += sum(int(counts[:D_shard(n, r, parts_n)].sum()) % 2 for r in range(1, parts_n))
+            assert odd > 0, "no shard in this test started on an odd nibble"
+            mask = np.arange(1024) % 3 != 0
+            assert np.array_equal(multi.eval_structs(structs, mask).view(np.uint32), want[mask].view(np.uint32))
+            with pytest.raises(ValueError):
+                multi(golden["piece_filters"][:-1], golden["occupied_bbs"])
+            # the native search takes the multi-device evaluator through the same function-pointer signature
+            s = search.Search.on_gpu(multi, use_policy=False, max_batch_size=2048)
+            s1 = search.Search.on_gpu(single, use_policy=False, max_batch_size=2048)
+            fen = "r3k2r/p1ppqpb1/bn2pnp1/3PN3/1p2P3/2N2Q1p/PPPBBPPP/R3K2R w KQkq - 0 1"
+            assert s.mtd_f(fen, 2)[0] == s1.mtd_f(fen, 2)[0]
+            s.close()
+            s1.close()
+        finally:
+            close_multi()
+    finally:
+        close_single()
+
+
+def D_shard(n, r, parts):
+    from batch_first_amd.distributed import shard_range
+    return shard_range(n, r, parts)[0]

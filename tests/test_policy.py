@@ -211,10 +211,46 @@ def test_policy_bf16_precision(pweights, pgolden, golden):
     rms = float(np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
     gap = 4 * 5e-2 * rms
     pos, checked = 0, 0
-    for k in pgolden["moves_per_board"]:
+    for k in pgolden["moves_per_board"].astype(np.int64):   # int64: a uint8 running sum wraps at 256
+        k = int(k)
         r, g = ref[pos:pos + k].astype(np.float64), got[pos:pos + k].astype(np.float64)
+        assert len(r) == k
         sep = (r[:, None] - r[None, :]) > gap
         assert np.all((g[:, None] - g[None, :])[sep] > 0)
         checked += int(sep.sum())
         pos += k
+    assert pos == len(ref)
     assert checked > 1000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_policy_orders_the_legal_moves_of_real_parents(pweights, dtype):
+    """The move-scoring network on what the search feeds it: the 128 parents of
+    tests/golden/siblings_128.npz with ALL their legal moves as requests in the mover's frame
+    (numba_negamax_zero_window.py:485-527).  float32: scores within REL_TOL of the oracle.  bf16 (no
+    reference counterpart): within 4e-2 * max(|r|, rms), and the moves of a parent keep their order and
+    their best move wherever float32 separates them by more than 4x that tolerance (x rms)."""
+    import os
+    from test_gpu_bf16 import ordering_report
+    from batch_first_amd import chestimator
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "siblings_128.npz")) as z:
+        sib = {k: z[k] for k in z.files}
+    bp, start, closer = chestimator.get_inference_functions(W.make_weights(seed=1234, bn="perturbed"), dtype=dtype,
+                                                            policy_weights=pweights)
+    try:
+        structs = np.frombuffer(sib["parent_records"].tobytes(), dtype=P.COMPACT_DTYPE)
+        nib, occ = E.struct_array_to_ann_inputs(structs)
+        got = start(nib, occ)([sib["from_squares"], sib["move_filters"], sib["group_sizes"]])
+    finally:
+        closer()
+    ref = sib["policy_scores_f32"]
+    worst = _ok(got, ref)
+    rms = float(np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
+    tol = REL_TOL if dtype == "f32" else 4e-2
+    print("%s policy on real move lists: worst error / rms-floored magnitude %.2e" % (dtype, worst))
+    assert worst <= tol
+    rep = ordering_report(got, ref, sib["group_sizes"], 4 * tol * rms)
+    print("policy ordering: %d best moves and %d pairs kept above the gap; %d of %d pairs differ below it"
+          % (rep["top_checked"], rep["pairs_checked"], rep["flipped_below_gap"], rep["pairs"]))
+    assert rep["groups"] == 128 and rep["pairs_checked"] > (40000 if dtype == "f32" else 1000)

@@ -140,3 +140,96 @@ def test_python_callable_as_evaluator():
     assert value == S.negamax(FENS[1], 2)
     assert calls and max(calls) <= 64
     s.close()
+
+
+def test_legality_sweep_all_from_to_promotion_triples():
+    """move_verification_tester (code_testing.py:266-293) on DEFAULT_MOVES_TO_CHECK (:55-59): all
+    64 * 63 * 5 (from, to, promotion) triples x the 7 positions.  The reference holds is_legal_move
+    against python-chess, which is not installed; here two independent decisions must agree on every
+    triple: membership in the generated legal moves (pinned by the perft tables above) and
+    is_legal_direct, which judges the move alone (numba_board.py:1149-1151's construction)."""
+    import itertools
+    triples = np.array([[a, b, p] for (a, b) in itertools.permutations(range(64), 2) for p in (0, 2, 3, 4, 5)], np.uint8)
+    assert triples.shape == (64 * 63 * 5, 3)
+    for fen, counts in zip(FENS, PERFT):
+        by_generator, direct = S.is_legal(fen, triples)
+        assert np.array_equal(by_generator, direct), (fen, triples[by_generator != direct][:5])
+        assert int(by_generator.sum()) == counts[0]          # every legal move is one of the triples
+        legal = {tuple(m) for m in S.legal_moves(fen)}
+        assert {tuple(t) for t in triples[by_generator]} == legal
+    # moves the sweep cannot phrase: same square, out of range, king promotion
+    g, d = S.is_legal(FENS[0], [[12, 12, 0], [12, 200, 0], [4, 12, 6], [12, 28, 5]])
+    assert not g.any() and not d.any()
+
+
+def test_legality_sweep_on_random_legal_positions():
+    """The same agreement on positions from random playouts (en passant, promotions, checks, pins and
+    castling through attacked squares turn up there), on the moves that matter: every generated move and
+    every other triple from the squares of the side to move."""
+    import itertools
+    triples = np.array([[a, b, p] for (a, b) in itertools.permutations(range(64), 2) for p in (0, 2, 5)], np.uint8)
+    fens = []
+    for seed in range(1, 7):
+        fen = FENS[seed % len(FENS)]
+        for step in range(40):
+            mv = S.legal_moves(fen)
+            if len(mv) == 0:
+                break
+            fen = S.push(fen, mv[(seed * 7919 + step * 104729) % len(mv)])
+            if step % 4 == 3:
+                fens.append(fen)
+    assert len(fens) >= 30
+    for fen in fens:
+        g, d = S.is_legal(fen, triples)
+        assert np.array_equal(g, d), (fen, triples[g != d][:5])
+
+
+def test_incremental_hash_over_random_lines():
+    """zobrist_hash_test (code_testing.py:86-136): 1000 random lines of up to 20 plies from the start
+    position (and 200 from each other test position): at every ply the hash carried along by push()
+    equals the hash computed from scratch.  The VALUES are unpinned (python-chess's Polyglot array is
+    not available offline, board.h); the update rules are what this pins."""
+    n, bad = S.hash_walk(FENS[0], lines=1000, plies=20, seed=11)
+    assert n > 19000 and bad == 0
+    for i, fen in enumerate(FENS[1:]):
+        n, bad = S.hash_walk(fen, lines=200, plies=20, seed=100 + i)
+        assert n > 2000 and bad == 0, fen
+
+
+# bf_piece_sum_eval's value table (code_testing.py:520-521), worked out by hand from the FEN text:
+# mover's material minus opponent's, P N B R Q = 100 300 300 500 900 (a castling rook counts as a rook).
+#   1 start 0 | 2 kiwipete 3900 - 3900 | 3 800 - 800 | 4 white 3900 (8P 2N 2B 2R Q) - black 3800 (7p ...) = +100
+#   5 the mirror, black to move: +100 | 6 3700 - 3700 | 7 3900 - 3900
+MATERIAL_KAT = [0, 0, 0, 100, 100, 0, 0]
+EXTRA_KAT = [("8/P6k/8/8/8/8/8/K7 w - - 0 1", 100), ("8/P6k/8/8/8/8/8/K7 b - - 0 1", -100),
+             ("4k3/8/8/8/8/8/8/R3K2R w KQ - 0 1", 1000), ("r3k2r/8/8/8/8/8/8/4K3 w kq - 0 1", -1000),
+             ("4k3/8/8/3q4/8/8/8/1NB1K3 b - - 0 1", 300)]
+
+
+def test_material_known_answers_native_and_wire_consumer():
+    """The reference's fake evaluator, two ways, against hand-computed values: the native
+    bfs_material_eval on node records and the oracle's restatement of bf_piece_sum_eval on the WIRE
+    format (which proves nibble order, mover's frame and the code table end to end)."""
+    import ctypes
+    from batch_first_amd import positions as P
+    lib = S.load()
+    cases = list(zip(FENS, MATERIAL_KAT)) + EXTRA_KAT
+    recs = np.stack([S.record_from_fen(f) for f, _ in cases])
+    want = np.array([v for _, v in cases], np.float32)
+    got = np.zeros(len(cases), np.float32)
+    done = ctypes.c_size_t(0)
+    assert lib.bfs_material_eval(None, recs.ctypes.data, 88, None, len(cases), got.ctypes.data, ctypes.byref(done)) == 0
+    assert done.value == len(cases) and np.array_equal(got, want)
+    structs = np.frombuffer(recs.tobytes(), dtype=P.COMPACT_DTYPE)
+    nib, occ = E.struct_array_to_ann_inputs(structs)
+    assert np.array_equal(E.bf_piece_sum_eval(nib, occ), want.astype(np.int64))
+
+
+def test_push_record_matches_push_on_fens():
+    for fen in FENS:
+        rec = S.record_from_fen(fen)
+        for mv in S.legal_moves(fen)[:12]:
+            child = S.push_record(rec, mv)
+            assert np.array_equal(child[:82], S.record_from_fen(S.push(fen, mv))[:82])
+    with pytest.raises(RuntimeError):
+        S.push_record(S.record_from_fen(FENS[0]), [12, 36, 0])
