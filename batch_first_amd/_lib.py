@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libbatchfirst_hip.so")
 
 BF_OK, BF_E_ARG, BF_E_HIP, BF_E_FORMAT, BF_E_NOGPU = 0, -1, -2, -3, -4
 BF_PRECISION_F32, BF_PRECISION_BF16 = 0, 1
+BF_NOALLOC_MAX_BOARDS = 262144
 PRECISIONS = {"f32": BF_PRECISION_F32, "fp32": BF_PRECISION_F32, "float32": BF_PRECISION_F32,
               "bf16": BF_PRECISION_BF16, "bfloat16": BF_PRECISION_BF16}
 
@@ -35,6 +36,7 @@ SIGNATURES = {
     "bf_ctx_destroy": (None, [_vp]),
     "bf_eval_wire": (_int, [_vp, _vp, _sz, _vp, _sz, _vp, _vp]),
     "bf_eval_structs": (_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
+    "bf_eval_structs_noalloc": (_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
     "bf_encode_planes_wire": (_int, [_vp, _vp, _sz, _vp, _sz, _vp, _vp]),
     "bf_encode_planes_structs": (_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
     "bf_encode_mailbox_wire": (_int, [_vp, _vp, _sz, _vp, _sz, _vp, _vp]),

@@ -47,6 +47,7 @@ struct Lane {
 
 struct bf_ctx : Lane {               // the base is the value network's lane
     int device = 0;
+    uint8_t* d_static_mailbox = nullptr;  // this device's copy of `scratch` (bf_eval_structs_noalloc)
     int precision = BF_PRECISION_F32;
     float* d_packed = nullptr;            // fp32 image (bf_layout.h) when precision == BF_PRECISION_F32
     unsigned char* d_image16 = nullptr;   // bf16 image (bf_layout_bf16.h) when precision == BF_PRECISION_BF16
@@ -149,6 +150,31 @@ int read_err_flag(Lane* c, hipStream_t s) {
 
 constexpr size_t kMaxBoards = (size_t)1 << 26;
 
+// ---- scratch of the allocation-free entry point (bf_eval_structs_noalloc) -----------------------
+// The mailboxes of one call, uint8 [BF_NOALLOC_MAX_BOARDS][32] = 8 MiB, in a file-scope device array:
+// every GPU the library runs on holds its own copy, at its own address, until the process ends.  In
+// host code the array's NAME is only a handle for hipGetSymbolAddress (passing it to a kernel would
+// compile and fault); the per-device address is looked up once, with that device current, when the
+// first context on the device is created, and only that pointer is used afterwards.
+static __device__ __align__(256) unsigned char scratch[BF_NOALLOC_MAX_BOARDS * 32];
+constexpr int kMaxDevices = 64;
+unsigned char* g_scratch_ptr[kMaxDevices] = {};
+std::mutex g_scratch_mu;
+
+// `device` must be the current device.
+int static_scratch_address(int device, uint8_t** out) {
+    if (device < 0 || device >= kMaxDevices) return bf::fail(BF_E_ARG, "device index %d is beyond the %d this library keeps scratch for", device, kMaxDevices);
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) return bf::fail(BF_E_HIP, "hipGetSymbolAddress(scratch) on device %d: %s", device, hipGetErrorString(e));
+        g_scratch_ptr[device] = static_cast<unsigned char*>(p);
+    }
+    *out = g_scratch_ptr[device];
+    return BF_OK;
+}
+
 int check_common(const bf_ctx* c, size_t n, const char* who) {
     if (!c) return bf::fail(BF_E_ARG, "%s: null context", who);
     if (n > kMaxBoards) return bf::fail(BF_E_ARG, "%s: %zu boards exceeds the limit of %zu per call", who, n, kMaxBoards);
@@ -214,6 +240,7 @@ extern "C" int bf_ctx_create_ex(bf_ctx** out, int device, const float* h_weights
         if (hipEventCreateWithFlags(&lane->scratch_done, hipEventDisableTiming) != hipSuccess)
             return bail(bf::fail(BF_E_HIP, "bf_ctx_create: event creation failed"));
     }
+    if (int r = static_scratch_address(device, &c->d_static_mailbox)) return bail(r);
     *out = c;
     return BF_OK;
 }
@@ -330,6 +357,27 @@ extern "C" int bf_eval_structs(bf_ctx* c, const void* d_structs, size_t stride, 
     BF_HIP(bf::launch_mailbox_from_structs(d_structs, stride, n, c->d_mailbox, (hipStream_t)stream));
     BF_HIP(launch_eval(c, c->d_mailbox, n, d_scores, nullptr, (hipStream_t)stream));
     return scratch_release(c, (hipStream_t)stream);
+}
+
+// Variant of bf_eval_structs for callers that cannot allocate: the mailboxes between the two kernels
+// live in this device's copy of `scratch` (see above), nothing is allocated, grown or freed, no lock is
+// taken and nothing synchronises.  Every mailbox the evaluation reads ([0, n)) is written by the
+// encode kernel of the same call first, so the array needs no clearing between calls; calls that
+// overlap on one GPU (two streams, two contexts, two threads) share it and race.
+extern "C" int bf_eval_structs_noalloc(bf_ctx* c, const void* d_structs, size_t stride, size_t n, float* d_scores,
+                                       void* stream) {
+    if (!c) return bf::fail(BF_E_ARG, "bf_eval_structs_noalloc: null context");
+    if (n > BF_NOALLOC_MAX_BOARDS)
+        return bf::fail(BF_E_ARG, "bf_eval_structs_noalloc: %zu boards exceeds the static scratch of %u boards per call "
+                        "(split the batch, or use bf_eval_structs)", n, (unsigned)BF_NOALLOC_MAX_BOARDS);
+    if (n == 0) return BF_OK;
+    if (!d_structs || !d_scores) return bf::fail(BF_E_ARG, "bf_eval_structs_noalloc: null pointer");
+    if (stride < BF_NODE_EVAL_BYTES) return bf::fail(BF_E_ARG, "bf_eval_structs_noalloc: stride %zu < 82", stride);
+    DeviceGuard guard(c->device);
+    uint8_t* const mailbox = c->d_static_mailbox;   // the looked-up device address, never the array's name
+    BF_HIP(bf::launch_mailbox_from_structs(d_structs, stride, n, mailbox, (hipStream_t)stream));
+    BF_HIP(launch_eval(c, mailbox, n, d_scores, nullptr, (hipStream_t)stream));
+    return BF_OK;
 }
 
 extern "C" int bf_eval_mailbox_debug(bf_ctx* c, const uint8_t* d_mailbox, size_t n, float* d_scores, float* d_debug,

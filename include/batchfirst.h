@@ -117,6 +117,20 @@ int bf_eval_wire(bf_ctx* ctx, const uint8_t* d_piece_filters, size_t n_bytes,
 int bf_eval_structs(bf_ctx* ctx, const void* d_structs, size_t stride, size_t n,
                     float* d_scores, void* stream);
 
+/* The same call for callers that cannot allocate device memory: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.
+ * bf_eval_structs keeps the 4-bit mailboxes between its two kernels in scratch that the context
+ * allocates and grows on demand; here they live in a file-scope device array of the library
+ * (8 MiB on every GPU the library runs on, held until the process ends), so the call allocates,
+ * grows and frees nothing, takes no lock and synchronises nothing.  Same scores, bit for bit.
+ * Limit: n <= BF_NOALLOC_MAX_BOARDS per call (BF_E_ARG beyond it).  All calls on one GPU share the
+ * array: calls that overlap in time on one GPU (two streams, two contexts, two threads) race;
+ * calls in stream order do not.  (Creating the context does allocate: do that outside the
+ * restricted region.) */
+#define BF_NOALLOC_MAX_BOARDS 262144u
+int bf_eval_structs_noalloc(bf_ctx* ctx, const void* d_structs, size_t stride, size_t n,
+                            float* d_scores, void* stream);
+
 /* ---- encoding alone, device pointers (for the bit-exact check and the HBM figure) ---- */
 
 /* Wire format -> planes.  Stands in for parse_into_ann_input_inference,
