@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbatchfirst_hip.so")
+# BATCHFIRST_LIB: another build of the same library (A/B timing and diagnostics, tools/build_t16_variant.sh)
+LIB_PATH = os.environ.get("BATCHFIRST_LIB") or os.path.join(_HERE, "libbatchfirst_hip.so")
 
 BF_OK, BF_E_ARG, BF_E_HIP, BF_E_FORMAT, BF_E_NOGPU = 0, -1, -2, -3, -4
 BF_PRECISION_F32, BF_PRECISION_BF16 = 0, 1
@@ -65,6 +66,8 @@ SIGNATURES = {
     "bf_policy_finish_host": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _vp]),
     "bf_packed_bf16_bytes": (_sz, []),
     "bf_pack_weights_bf16": (_int, [_vp, _sz, _vp, _sz]),
+    "bf_packed_t16_bytes": (_sz, []),
+    "bf_pack_weights_t16": (_int, [_vp, _sz, _vp, _sz]),
     # debugging aids, not part of the public header
     "bf_eval_mailbox_debug": (_int, [_vp, _vp, _sz, _vp, _vp, _vp]),
     "bf_debug_floats_per_board": (_sz, []),

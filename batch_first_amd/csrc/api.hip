@@ -1,6 +1,7 @@
 // C-ABI entry points (include/batchfirst.h): context, device and host evaluation calls.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -11,6 +12,7 @@
 #include "bf_kernels.h"
 #include "bf_layout.h"
 #include "bf_layout_bf16.h"
+#include "bf_layout_t16.h"
 
 #define BF_HIP(call)                                                                         \
     do {                                                                                     \
@@ -49,6 +51,9 @@ struct bf_ctx : Lane {               // the base is the value network's lane
     int device = 0;
     uint8_t* d_static_mailbox = nullptr;  // this device's copy of `scratch` (bf_eval_structs_noalloc)
     int precision = BF_PRECISION_F32;
+    // which bf16 kernel a BF16 context runs: the 16x16x32 one (eval_t16.hip) unless the environment variable
+    // BF_BF16_TILES=32 asked for its 32x32x16 predecessor when the context was created (A/B timing)
+    bool tiles32 = false;
     float* d_packed = nullptr;            // fp32 image (bf_layout.h) when precision == BF_PRECISION_F32
     unsigned char* d_image16 = nullptr;   // bf16 image (bf_layout_bf16.h) when precision == BF_PRECISION_BF16
     // move-scoring network (bf_ctx_set_policy)
@@ -116,7 +121,9 @@ int ensure_staging(Lane* c, size_t in_bytes, size_t n_scores) {
 
 // The value network in the context's precision.
 hipError_t launch_eval(bf_ctx* c, const uint8_t* d_mailbox, size_t n, float* d_scores, float* d_debug, hipStream_t s) {
-    if (c->precision == BF_PRECISION_BF16) return bf::launch_eval_bf16(d_mailbox, n, c->d_image16, d_scores, d_debug, s);
+    if (c->precision == BF_PRECISION_BF16)
+        return c->tiles32 ? bf::launch_eval_bf16(d_mailbox, n, c->d_image16, d_scores, d_debug, s)
+                          : bf::launch_eval_t16(d_mailbox, n, c->d_image16, d_scores, d_debug, s);
     return bf::launch_eval_f32(d_mailbox, n, c->d_packed, d_scores, d_debug, s);
 }
 
@@ -218,8 +225,12 @@ extern "C" int bf_ctx_create_ex(bf_ctx** out, int device, const float* h_weights
         return code;
     };
     if (precision == BF_PRECISION_BF16) {
+        static_assert(bf::b16::kImageBytes == bf::t16::kImageBytes && bf::b16::kOffHead == bf::t16::kOffHead, "one allocation size, one logit offset");
+        const char* env = std::getenv("BF_BF16_TILES");
+        c->tiles32 = env && std::strcmp(env, "32") == 0;
         std::vector<unsigned char> image(bf::b16::kImageBytes);
-        bf::pack_weights_bf16(h_weights, image.data());
+        if (c->tiles32) bf::pack_weights_bf16(h_weights, image.data());
+        else bf::pack_weights_t16(h_weights, image.data());
         if (hipMalloc(&c->d_image16, image.size()) != hipSuccess)
             return bail(bf::fail(BF_E_HIP, "bf_ctx_create: hipMalloc of the weight image failed"));
         if (hipMemcpy(c->d_image16, image.data(), image.size(), hipMemcpyHostToDevice) != hipSuccess)
@@ -654,7 +665,9 @@ int check_policy(const bf_ctx* c, size_t n, const char* who) {
 }
 
 hipError_t launch_policy_features(bf_ctx* c, const uint8_t* d_mailbox, size_t n, float* d_x9, hipStream_t s) {
-    if (c->precision == BF_PRECISION_BF16) return bf::launch_policy_features_bf16(d_mailbox, n, c->d_policy_image16, d_x9, s);
+    if (c->precision == BF_PRECISION_BF16)
+        return c->tiles32 ? bf::launch_policy_features_bf16(d_mailbox, n, c->d_policy_image16, d_x9, s)
+                          : bf::launch_policy_features_t16(d_mailbox, n, c->d_policy_image16, d_x9, s);
     return bf::launch_policy_features_f32(d_mailbox, n, c->d_policy_packed, d_x9, s);
 }
 
@@ -685,7 +698,8 @@ extern "C" int bf_ctx_set_policy(bf_ctx* c, const float* h_weights, size_t n_flo
     BF_HIP(hipStreamSynchronize(c->policy.stream));
     if (c->precision == BF_PRECISION_BF16) {
         std::vector<unsigned char> image(bf::b16::kImageBytes);
-        bf::pack_weights_bf16(h_weights, image.data(), true);
+        if (c->tiles32) bf::pack_weights_bf16(h_weights, image.data(), true);
+        else bf::pack_weights_t16(h_weights, image.data(), true);
         if (!c->d_policy_image16) BF_HIP(hipMalloc(&c->d_policy_image16, image.size()));
         BF_HIP(hipMemcpy(c->d_policy_image16, image.data(), image.size(), hipMemcpyHostToDevice));
     } else {

@@ -16,6 +16,9 @@ void pack_weights(const float* blob, float* packed, bool policy = false);
 // canonical blob -> bf16 image (bf_layout_bf16.h), b16::kImageBytes bytes
 void pack_weights_bf16(const float* blob, unsigned char* image, bool policy = false);
 
+// canonical blob -> image of the 16x16x32 bf16 kernel (bf_layout_t16.h), t16::kImageBytes bytes
+void pack_weights_t16(const float* blob, unsigned char* image, bool policy = false);
+
 // Host restatement of one record's relevance mask and codes, shared by the host encoder.
 // codes_out receives popcount(mask) codes in ascending square order (mover's frame).
 uint64_t host_board_codes(const unsigned char* rec, uint8_t* codes_out, int* n_codes);

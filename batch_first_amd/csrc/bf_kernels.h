@@ -49,4 +49,10 @@ hipError_t launch_policy_scores(const float* d_x9, const float* d_logit_w, const
 hipError_t launch_eval_bf16(const uint8_t* d_mailbox, size_t n, const unsigned char* d_image, float* d_scores,
                             float* d_debug, hipStream_t stream);
 
+// The bf16 network on v_mfma_f32_16x16x32_bf16 (eval_t16.hip); `d_image` is the image bf::pack_weights_t16 builds.
+hipError_t launch_eval_t16(const uint8_t* d_mailbox, size_t n, const unsigned char* d_image, float* d_scores,
+                           float* d_debug, hipStream_t stream);
+hipError_t launch_policy_features_t16(const uint8_t* d_mailbox, size_t n, const unsigned char* d_image, float* d_x9,
+                                      hipStream_t stream);
+
 }  // namespace bf

@@ -1,0 +1,767 @@
+// The value network as one bf16 kernel on v_mfma_f32_16x16x32_bf16 (BASELINE configs[2]): 4-bit mailboxes
+// in, one score per board out.  Arithmetic and weight image: bf_layout_t16.h.  Successor of eval_bf16.hip
+// (32x32x16 tiles), same structure around the arithmetic: persistent workgroups (one per compute unit),
+// one wave = one board, the weight stream walked as a ring through LDS by LDS-DMA, every stage a flat,
+// fully unrolled list of MFMA slots with the LDS reads, packs and LDS writes of its neighbours in the gaps.
+//
+// Reference graph replaced (TensorFlow ops -> this kernel):
+//   create_input_convolutions_shared_weights   ann_creation_helper.py:192-252  (stage 1)
+//   build_convolutional_modules, spec at       evaluation_ann.py:268           (stages 2-4)
+//   logit_layer + squeeze                      evaluation_ann.py:35-46         (stage 5)
+//
+// Why this shape: the 32x32x16 kernel is limited by the clock the chip holds under its
+// load; in a bare loop the 16x16x32 instruction delivers 9-15 % more FLOP/s at that limit.  A board's 64
+// squares are four 16-column tiles (ranks 2t, 2t+1), every 1-KiB weight fragment read from LDS feeds four
+// MFMAs, and every layer has four independent accumulation chains, which is what hides the
+// pack -> LDS write -> shifted read chain of the 3x3 layers: within a layer the column tiles run one
+// after the other (the layer's 18 fragments stay in registers after the first), and the tile a column
+// tile needs from the previous layer was finished at least two tiles earlier.
+//   stage 1  B operand of a k-step = two taps x 16 planes: lanes q = 0,1 look up tap A's shifted square,
+//            q = 2,3 tap B's (a code byte from the padded byte mailbox, then that code's one-hot row from
+//            a 16-entry table); a step whose taps all miss the board for a column tile is skipped there.
+//   stage 2  per pair of 16-row hidden tiles: 16 fragments (236->512), ReLU + pack, 8 fragments (512->128),
+//            software-pipelined across pairs (stream order kPairOrder).
+//   stage 3/4  3x3 layers through zero-haloed [10x10 positions][32 channels] bf16 planes private to the
+//            wave; a position's 16-byte channel chunk q sits at chunk (q + padded file) & 3, which makes
+//            the shifted ds_read_b128 of every tap conflict-free and the ds_write_b128 two-way at worst.
+//   stage 5  8x8 valid conv across the workgroup's boards (one MFMA per square), ReLU, logit.
+// Results are bit-reproducible and independent of a board's position in the batch.
+#include <hip/hip_runtime.h>
+
+#include "bf_device.h"
+#include "bf_kernels.h"
+#include "bf_layout_t16.h"
+
+namespace bf {
+
+namespace t16 {
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BPB = 4;                   // boards per workgroup = waves per workgroup
+constexpr int WAVES = BPB;
+constexpr int THREADS = 64 * WAVES;
+constexpr int CHUNK = 16;                // groups per lockstep chunk of the weight ring
+constexpr int SHARE = CHUNK / WAVES;     // groups each wave fetches per chunk
+constexpr int SLOTS = 4;                 // ring slots
+#ifndef T16_LA
+#define T16_LA 7
+#endif
+constexpr int LA = T16_LA;               // groups held in registers ahead of the MFMAs
+constexpr int AHEAD = SLOTS - 2;         // chunks the refill runs ahead of the chunk being read
+constexpr int WALK_CHUNKS = kStreamWalkGroups / CHUNK;
+static_assert(kStreamWalkGroups % CHUNK == 0 && WALK_CHUNKS % SLOTS == 0 && kStreamWalkGroups % (LA + 1) == 0,
+              "every board starts in the same phase of the ring and of the register look-ahead");
+static_assert(SHARE == 4, "fetch_piece: four pieces with immediate offsets");
+
+constexpr int MB_W = 22;                 // byte mailbox padded by 7 squares on every side
+constexpr int MB_WORDS = 124;
+constexpr int XP_W = 10;                 // activation plane padded by 1
+constexpr int POS_BYTES = 64;            // 32 channels bf16
+constexpr int ROW_BYTES = XP_W * POS_BYTES;            // 640
+constexpr int PLANE_BYTES = XP_W * ROW_BYTES;          // 6400
+constexpr int BOARD_BYTES = 2 * PLANE_BYTES;
+static_assert(MB_WORDS * 4 <= PLANE_BYTES, "the byte mailbox aliases plane 0");
+
+struct Lds {
+    f32x4 wring[SLOTS][CHUNK][64];                       // shared A-fragment ring, 64 KiB
+    __attribute__((aligned(16))) unsigned char board[BPB][BOARD_BYTES];
+    u32x4 onehot[16][2];                                 // stage 1: [code][plane half] -> 8 bf16 planes
+    __attribute__((aligned(16))) float bias3[6 * 32];    // shifts of x4..x9: [layer][row tile][q][r]
+    __attribute__((aligned(16))) float bias2[128];       // shifts of x3: [row tile][q][r]
+    f32x4 hpart[WAVES][64];                              // stage 5: per-wave partial sums
+    u32x4 headk[WAVES][8][64];                           // stage 5: the 8x8 kernels of each wave's squares 8..15 (the other eight live in registers)
+    __attribute__((aligned(16))) unsigned char next_mailbox[WAVES][256];
+};
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Chunk barrier of the weight ring (see eval_bf16.hip: ring_barrier): this wave's share of the chunk about
+// to be read has landed; (AHEAD - 1) * SHARE younger pieces (+ EXTRA: the mailbox prefetch) may stay in flight.
+template <int EXTRA>
+__device__ __forceinline__ void ring_barrier() {
+    constexpr int N = (AHEAD - 1) * SHARE + EXTRA;
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// The next board's mailbox is prefetched after the take of this group (the take that issues the last piece
+// of its chunk), early in stage 2.
+constexpr int kPrefetchGroup = ((kPairBase + 24 + LA + CHUNK - 1) / CHUNK) * CHUNK + SHARE - 1 - LA;
+static_assert((kPrefetchGroup + LA) % CHUNK == SHARE - 1 && kPrefetchGroup >= kPairBase &&
+              kPrefetchGroup + 3 * CHUNK < kStreamGroups, "");
+
+// Lockstep walk over the A-fragment stream through the LDS ring: as in eval_bf16.hip, whose comments give
+// the measurements behind each choice.  INVARIANT (tools/isa_hazards.py checks every build's listing): no
+// VALU write of an SGPR within five wait states in front of the asm LDS-DMA that reads it as its base, and
+// no compiler write of M0 -- the chunk base comes out of scalar adds inside an asm statement.
+struct WStream {
+    const unsigned char* sbase;
+    const unsigned char* sbase0;
+    unsigned voff;
+    unsigned lds_share;
+    f32x4* ring;
+    int rd;
+    int fill;
+    f32x4 pre[LA + 1];
+
+    __device__ __forceinline__ void set_m0(int slot_off) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(lds_share + (unsigned)slot_off * 16u) : "memory", "m0");
+    }
+    __device__ __forceinline__ void set_base(int chunk) {
+        const unsigned long long b0 = (unsigned long long)(uintptr_t)sbase0;
+        unsigned lo, hi;
+        asm volatile("s_add_u32 %0, %2, %4\n\ts_addc_u32 %1, %3, 0"
+                     : "=&s"(lo), "=s"(hi)
+                     : "s"((unsigned)b0), "s"((unsigned)(b0 >> 32)), "s"((unsigned)(chunk * CHUNK * 1024))
+                     : "scc");
+        sbase = reinterpret_cast<const unsigned char*>((uintptr_t)(((unsigned long long)hi << 32) | lo));
+    }
+    __device__ __forceinline__ void fetch_piece(int i) {
+        if (i == 0) asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase) : "memory");
+        if (i == 1) asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" ::"v"(voff), "s"(sbase) : "memory");
+        if (i == 2) asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" ::"v"(voff), "s"(sbase) : "memory");
+        if (i == 3) asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" ::"v"(voff), "s"(sbase) : "memory");
+    }
+    __device__ __forceinline__ void prefetch_mailbox(const unsigned char* board_bytes, unsigned lds_dst, int lane) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2"
+                     ::"s"(lds_dst), "v"((unsigned)(lane & 7) * 4u), "s"(board_bytes) : "memory", "m0");
+    }
+    __device__ __forceinline__ void prime(const f32x4* stream, f32x4* ring_base, int lane, int wave) {
+        typedef __attribute__((address_space(3))) f32x4* lds_ptr;
+        ring = ring_base + lane;
+        lds_share = (unsigned)(uintptr_t)(lds_ptr)(ring_base + wave * SHARE * 64);
+        sbase0 = sbase = reinterpret_cast<const unsigned char*>(stream + wave * SHARE * 64);
+        voff = (unsigned)lane * 16u;
+#pragma unroll
+        for (int c = 0; c < AHEAD; ++c) {
+            set_m0(c * CHUNK * 64);
+            set_base(c);
+#pragma unroll
+            for (int i = 0; i < SHARE; ++i) fetch_piece(i);
+        }
+        rd = (SLOTS - 1) * CHUNK * 64;
+    }
+    template <int EXTRA>
+    __device__ __forceinline__ void next_chunk() {
+        rd = (rd == (SLOTS - 1) * CHUNK * 64) ? 0 : rd + CHUNK * 64;
+        __builtin_amdgcn_sched_barrier(0);
+        ring_barrier<EXTRA>();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void aim_refill(int chunk) {
+        fill = rd + (AHEAD + 1) * CHUNK * 64;
+        while (fill >= SLOTS * CHUNK * 64) fill -= SLOTS * CHUNK * 64;
+        set_m0(fill);
+        set_base(chunk % WALK_CHUNKS);
+    }
+    __device__ __forceinline__ void refill_step(int i, int c) {
+        if (i < SHARE) fetch_piece(i);
+        if (i == SHARE) aim_refill(c + 1 + AHEAD);
+    }
+    __device__ __forceinline__ void start() {
+        next_chunk<0>();
+        fill = rd + AHEAD * CHUNK * 64;
+        if (fill >= SLOTS * CHUNK * 64) fill -= SLOTS * CHUNK * 64;
+        set_m0(fill);
+        set_base(AHEAD);
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            refill_step(i, 0);
+            pre[i] = ring[rd + i * 64];
+        }
+    }
+    __device__ __forceinline__ void board_start() { rd = 0; }
+    // g: stream group index, a compile-time constant after unrolling; groups are taken in order.
+    __device__ __forceinline__ bf16x8 take(int g) {
+        const int nx = g + LA, i = nx % CHUNK;
+        const bool extra = nx > kPrefetchGroup + LA && nx <= kPrefetchGroup + LA + AHEAD * CHUNK;
+        if (i == 0) { if (extra) next_chunk<1>(); else next_chunk<0>(); }
+        refill_step(i, nx / CHUNK);
+        pre[nx % (LA + 1)] = ring[rd + i * 64];
+        __builtin_amdgcn_sched_barrier(0);
+        return __builtin_bit_cast(bf16x8, pre[g % (LA + 1)]);
+    }
+};
+
+// bf16(max(a, 0)), bf16(max(b, 0)) packed low / high (one v_cvt_pk_bf16_f32 + one signed 16-bit max)
+__device__ __forceinline__ unsigned pack_relu(float a, float b) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const bf16x2 v = __builtin_convertvector(f32x2{a, b}, bf16x2);
+    s16x2 s = __builtin_bit_cast(s16x2, v);
+    s = __builtin_elementwise_max(s, s16x2{0, 0});
+    return __builtin_bit_cast(unsigned, s);
+}
+__device__ __forceinline__ float bf16_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xFFFF0000u); }
+
+#ifdef BF_STAMPS
+#define BF_STAMP(i) do { stamps[i] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BF_STAMP(i) ((void)0)
+#endif
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
+
+// ---- stage 1 as a flat list of units = (conv, step, column tile) that are computed -------------------
+constexpr int kMaxUnits = 176, kMaxJobs = 8;
+struct S1Table {
+    int n;
+    short conv[kMaxUnits], step[kMaxUnits], t[kMaxUnits], g0[kMaxUnits];
+    short off_a[kMaxUnits], off_b[kMaxUnits];        // byte-mailbox offsets of the two taps (tile 0's square)
+    bool first_of_step[kMaxUnits], first_of_tile[kMaxUnits];
+    short njobs[kMaxUnits];
+    short job[kMaxUnits][kMaxJobs];                  // pack jobs run after the unit's MFMAs: t * 32 + dword
+    short ntail;
+    short tail[64];                                  // jobs left after the last unit
+};
+constexpr S1Table make_s1_table() {
+    S1Table T{};
+    int n = 0, g = 0;
+    int last_unit_of_conv[kNumInputConvs] = {};
+    int first_unit_of_conv[kNumInputConvs + 2] = {};
+    for (int i = 0; i < kNumInputConvs; ++i) {
+        first_unit_of_conv[i] = n;
+        bool seen[4] = {false, false, false, false};
+        for (int s = 0; s < steps_of(i); ++s) {
+            const TapPair tp = step_taps(i, s);
+            bool first = true;
+            for (int t = 0; t < 4; ++t) {
+                if (!step_valid(i, s, t)) continue;
+                T.conv[n] = (short)i; T.step[n] = (short)s; T.t[n] = (short)t; T.g0[n] = (short)g;
+                T.off_a[n] = (short)(tap_dr(i, tp.a) * MB_W + tap_df(i, tp.a));
+                T.off_b[n] = tp.b >= 0 ? (short)(tap_dr(i, tp.b) * MB_W + tap_df(i, tp.b)) : T.off_a[n];
+                T.first_of_step[n] = first;
+                T.first_of_tile[n] = !seen[t];
+                first = false;
+                seen[t] = true;
+                ++n;
+            }
+            g += kRowTiles[i];
+        }
+        last_unit_of_conv[i] = n - 1;
+    }
+    first_unit_of_conv[kNumInputConvs] = first_unit_of_conv[kNumInputConvs + 1] = n;
+    T.n = n;
+    // pack jobs in order (conv, column tile, dword); a conv's jobs may start one unit after its last unit and
+    // must be done before conv + 2 starts (the accumulators alternate between two buffers)
+    int jc = 0, jt = 0, jd = 0;   // next job: conv jc, tile jt, dword jd (local to the conv)
+    auto job_code = [&](int c, int t, int d) { return (short)(t * 32 + kX1RegBase[c] / 2 + d); };
+    auto advance = [&]() {
+        if (++jd == kX1RegCount[jc] / 2) { jd = 0; if (++jt == 4) { jt = 0; ++jc; } }
+    };
+    for (int u = 0; u < n; ++u) {
+        int k = 0;
+        const bool flush = (u + 1 == n) ? false : (T.conv[u + 1] != T.conv[u]);   // last unit of its conv
+        while (jc < kNumInputConvs && last_unit_of_conv[jc] < u) {
+            const bool must = flush && jc + 1 <= T.conv[u];   // conv jc's buffer is overwritten by the next unit
+            if (k >= 2 && !must) break;
+            if (k >= kMaxJobs) break;
+            T.job[u][k++] = job_code(jc, jt, jd);
+            advance();
+        }
+        T.njobs[u] = (short)k;
+    }
+    int nt = 0;
+    while (jc < kNumInputConvs) { T.tail[nt++] = job_code(jc, jt, jd); advance(); }
+    T.ntail = (short)nt;
+    return T;
+}
+constexpr S1Table kS1 = make_s1_table();
+constexpr bool s1_jobs_meet_deadlines() {
+    // every job of conv c is placed in a unit of conv <= c + 1, or in the tail when c + 2 does not exist
+    for (int u = 0; u < kS1.n; ++u)
+        for (int k = 0; k < kS1.njobs[u]; ++k) {
+            const int d = kS1.job[u][k] % 32;
+            const int c = x1_slot(2 * d).conv;
+            if (kS1.conv[u] > c + 1 || kS1.conv[u] <= c) return false;
+        }
+    for (int k = 0; k < kS1.ntail; ++k)
+        if (x1_slot(2 * (kS1.tail[k] % 32)).conv + 2 < kNumInputConvs) return false;
+    return true;
+}
+static_assert(kS1.n <= kMaxUnits && kS1.ntail <= 64 && s1_jobs_meet_deadlines(), "");
+
+// ReLU + bf16 of x1 dword d of column tile t from the finished accumulators of its conv
+__device__ __forceinline__ unsigned s1_pack(int t, int d, const f32x4 (&acc)[2][4][4]) {
+    const X1Slot a = x1_slot(2 * d), b = x1_slot(2 * d + 1);
+    unsigned p = pack_relu(acc[a.conv & 1][a.tile][t][a.r], acc[b.conv & 1][b.tile][t][b.r]);
+    asm volatile("" : "+v"(p));   // pinned where it is scheduled (see eval_bf16.hip: the compiler sinks unpinned packs)
+    return p;
+}
+
+template <bool DBG>
+__device__ __forceinline__ void s1_dump(int t, int d, unsigned p, int q, int c16, float* dbg_board) {
+    if (!DBG) return;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const X1Slot s = x1_slot(2 * d + e);
+        const int local = tile_channel(s.tile, s.r, 0) + q;
+        if (local < kInputConvs[s.conv].ch)
+            dbg_board[(kInputConvs[s.conv].chan_base + local) * 64 + 16 * t + c16] = e ? bf16_hi(p) : bf16_lo(p);
+    }
+}
+
+// mb: this lane's square of column tile 0 in the byte mailbox; tbl: the one-hot table at this lane's plane
+// half; q2: lane quarter >= 2 (looks up the step's second tap).
+template <bool DBG>
+__device__ __forceinline__ void stage1(WStream& ws, const unsigned char* mb, const u32x4* tbl, bool q2, unsigned (&X)[4][kX1Dwords],
+                                       int q, int c16, float* dbg_board) {
+#ifndef T16_S1_Q
+#define T16_S1_Q 4
+#endif
+    constexpr int CQ = T16_S1_Q, BQ = T16_S1_Q, NC = CQ + BQ;   // codes run CQ + BQ units ahead, rows BQ units
+    constexpr int N = kS1.n;
+    int code[NC];
+    u32x4 b[BQ];
+    f32x4 acc[2][4][4];   // [conv parity][row tile][column tile]
+    bf16x8 fr[4];
+    auto read_code = [&](int u) -> int {
+        const int uu = u < N ? u : N - 1;   // look-ahead past the end re-reads the last unit (harmless)
+        const int off = q2 ? kS1.off_b[uu] : kS1.off_a[uu];
+        return mb[off + 2 * kS1.t[uu] * MB_W];
+    };
+#pragma unroll
+    for (int u = 0; u < NC; ++u) code[u] = read_code(u);
+#pragma unroll
+    for (int u = 0; u < BQ; ++u) b[u] = tbl[code[u] * 2];
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        const int I = kS1.conv[u], t = kS1.t[u], par = I & 1;
+        if (kS1.first_of_step[u]) {
+#pragma unroll
+            for (int tile = 0; tile < 4; ++tile)
+                if (tile < kRowTiles[I]) fr[tile] = ws.take(kS1.g0[u] + tile);
+        }
+        const bf16x8 bu = __builtin_bit_cast(bf16x8, b[u % BQ]);
+#pragma unroll
+        for (int tile = 0; tile < 4; ++tile)
+            if (tile < kRowTiles[I])
+                acc[par][tile][t] = MFMA16(fr[tile], bu, kS1.first_of_tile[u] ? zero4() : acc[par][tile][t]);
+        b[u % BQ] = tbl[code[(u + BQ) % NC] * 2];
+        code[u % NC] = read_code(u + NC);
+#pragma unroll
+        for (int k = 0; k < kMaxJobs; ++k)
+            if (k < kS1.njobs[u]) {
+                const int jt = kS1.job[u][k] / 32, jd = kS1.job[u][k] % 32;
+                X[jt][jd] = s1_pack(jt, jd, acc);
+                s1_dump<DBG>(jt, jd, X[jt][jd], q, c16, dbg_board);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int k = 0; k < 64; ++k)
+        if (k < kS1.ntail) {
+            const int jt = kS1.tail[k] / 32, jd = kS1.tail[k] % 32;
+            X[jt][jd] = s1_pack(jt, jd, acc);
+            s1_dump<DBG>(jt, jd, X[jt][jd], q, c16, dbg_board);
+        }
+}
+
+// Debug dump of a 16-row tile (channels 16 * tile_index + 4r + q of column tile t) as the bf16 values the
+// next layer sees.
+__device__ __forceinline__ void dump_tile(float* dst_ch0, int q, int sq, const f32x4& a) {
+    const unsigned p0 = pack_relu(a[0], a[1]), p1 = pack_relu(a[2], a[3]);
+    dst_ch0[(0 + q) * 64 + sq] = bf16_lo(p0);
+    dst_ch0[(4 + q) * 64 + sq] = bf16_hi(p0);
+    dst_ch0[(8 + q) * 64 + sq] = bf16_lo(p1);
+    dst_ch0[(12 + q) * 64 + sq] = bf16_hi(p1);
+}
+
+// MODE 0: scores; 1: scores + every intermediate activation (debug); 2: features -- x9 as float32
+// [board][32][64] into `scores`, no head (the move-scoring network).
+template <int MODE>
+__global__ __launch_bounds__(THREADS, 1) void k_eval_t16(const uint8_t* __restrict__ mailbox, unsigned n_boards,
+                                                          const f32x4* __restrict__ wstream,
+                                                          const float* __restrict__ bias,
+                                                          const f32x4* __restrict__ headw,
+                                                          float* __restrict__ scores, float* __restrict__ dbg) {
+    constexpr bool DBG = MODE == 1;
+    __shared__ __attribute__((aligned(16))) Lds lds;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, c16 = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rk = c16 >> 3, file = c16 & 7;                 // column tile 0's square; tile t is 2t ranks up
+    const unsigned n_quads = (n_boards + BPB - 1) / BPB;
+    typedef __attribute__((address_space(3))) unsigned char* lds_bytes;
+
+#ifdef BF_STAMPS
+    unsigned stamps[16] = {};
+#endif
+    WStream ws;
+    ws.prime(wstream, &lds.wring[0][0][0], lane, wave);
+
+    // ---- once per workgroup: the one-hot table, the shifts, the head kernels ---------------------------
+    unsigned char* region = lds.board[wave];
+    if (tid < 32) {
+        const unsigned c = tid >> 1, hh = tid & 1, j = c & 7u;
+        const unsigned one = (c != 15u && (c >> 3) == hh) ? (0x3F80u << ((j & 1u) * 16u)) : 0u;
+        u32x4 e = u32x4{0u, 0u, 0u, hh ? 0x3F800000u : 0u};  // plane 15 = 1.0 in every entry
+        e.x |= ((j >> 1) == 0u) ? one : 0u;
+        e.y |= ((j >> 1) == 1u) ? one : 0u;
+        e.z |= ((j >> 1) == 2u) ? one : 0u;
+        e.w |= ((j >> 1) == 3u) ? one : 0u;
+        lds.onehot[c][hh] = e;
+    }
+    for (int i = tid; i < 6 * 32; i += THREADS) lds.bias3[i] = bias[kBiasX4 + i];
+    for (int i = tid; i < 128; i += THREADS) lds.bias2[i] = bias[kBiasX3 + i];
+    constexpr int SQW = 64 / WAVES;  // squares (k-steps of the head) per wave
+    constexpr int SQR = SQW / 2;     // of which this many have their kernels in registers, the rest in LDS
+    u32x4 ha[SQR];
+    if (MODE != 2) {
+        const f32x4* hwp = headw + (size_t)wave * SQW * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < SQR; ++i) ha[i] = DBG ? u32x4{0u, 0u, 0u, 0u} : __builtin_bit_cast(u32x4, hwp[i * 64]);
+#pragma unroll
+        for (int i = SQR; i < SQW; ++i) lds.headk[wave][i - SQR][lane] = __builtin_bit_cast(u32x4, hwp[i * 64]);
+    }
+    const float head_shift = MODE != 2 ? bias[kBiasX10 + (tid & 15)] : 0.0f;
+    const float head_logit = MODE != 2 ? bias[kLogitW + (tid & 15)] : 0.0f;
+    for (int i = lane; i < 2 * PLANE_BYTES / 16; i += 64) reinterpret_cast<u32x4*>(region)[i] = u32x4{0u, 0u, 0u, 0u};
+    {   // the first board's mailbox directly (every later one is prefetched)
+        const unsigned b0 = blockIdx.x * BPB + wave;
+        const unsigned bc = b0 < n_boards ? b0 : n_boards - 1;
+        if (lane < 8)
+            reinterpret_cast<unsigned*>(lds.next_mailbox[wave])[lane] =
+                reinterpret_cast<const unsigned*>(mailbox + (size_t)bc * kMailboxBytes)[lane];
+    }
+    lds_order();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    ws.start();
+
+    // lane constants of the activation planes: padded file F = file + 1, chunk of quarter q at (q + F) & 3
+    const int waddr = ((rk + 1) * XP_W + file + 1) * POS_BYTES + (((q + file + 1) & 3) << 4);   // tile 0's square; tile t at + 2t rows
+    int raddr[3];   // shifted reads, df = -1, 0, +1, one padded row ABOVE the square (dr = -1): row offsets stay >= 0
+#pragma unroll
+    for (int d = 0; d < 3; ++d) raddr[d] = (rk * XP_W + file + d) * POS_BYTES + (((q + file + d) & 3) << 4);
+
+#pragma unroll 1
+    for (unsigned quad = blockIdx.x; quad < n_quads; quad += gridDim.x) {
+    const unsigned board_raw = quad * BPB + wave;
+    const unsigned board = board_raw < n_boards ? board_raw : n_boards - 1;  // padding boards repeat the last one
+    unsigned next_raw = (quad + gridDim.x) * BPB + wave;
+    const unsigned next_board = __builtin_amdgcn_readfirstlane(next_raw < n_boards ? next_raw : n_boards - 1);
+    ws.board_start();
+    BF_STAMP(0);
+#ifdef BF_STAMPS
+    stamps[7] = (unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
+
+    // ---- byte mailbox: 15 everywhere, then the board's codes -------------------------------------
+    static_assert(MB_WORDS <= 128, "");
+    reinterpret_cast<unsigned*>(region)[lane] = 0x0F0F0F0Fu;
+    reinterpret_cast<unsigned*>(region)[lane + 64] = 0x0F0F0F0Fu;
+    lds_order();
+    {
+        const unsigned v = lds.next_mailbox[wave][lane >> 1];
+        const unsigned c = (lane & 1) ? (v >> 4) : (v & 15u);
+        region[((lane >> 3) + 7) * MB_W + (lane & 7) + 7] = (unsigned char)c;
+    }
+    lds_order();
+
+    float* dbg_board = DBG ? dbg + (size_t)board * kDebugFloatsPerBoard : nullptr;
+    BF_STAMP(1);
+
+    // ---- stage 1: input convs -> x1 as 32 packed dwords per column tile ---------------------------
+    unsigned X[4][kX1Dwords];
+    {
+        const unsigned char* mb = region + (rk + 7) * MB_W + file + 7;
+        const u32x4* tbl = &lds.onehot[0][q & 1];
+        stage1<DBG>(ws, mb, tbl, q >= 2, X, q, c16, dbg_board);
+    }
+    // the byte mailbox is dead: its bytes are halo squares of plane 0 again (one unconditional 1-KiB store)
+    lds_order();
+    static_assert(MB_WORDS * 4 <= 1024 && 1024 <= PLANE_BYTES, "");
+    reinterpret_cast<u32x4*>(region)[lane] = u32x4{0u, 0u, 0u, 0u};
+
+    BF_STAMP(2);
+    // ---- stage 2: 1x1 236->512 (+ReLU) chained into 1x1 512->128 -----------------------------------
+    f32x4 acc3[kOutTiles][4];
+    {
+        f32x4 acc2[2][2][4];   // [pair parity][tile of the pair][column tile]
+        unsigned H[4][4];      // packed hidden pair: [column tile][dword]
+        f32x4 seed[kOutTiles];
+        auto pack_piece = [&](int par, int k) {   // k = 0..15: column tile k >> 2, dword k & 3
+            const int t = k >> 2, d = k & 3;
+            H[t][d] = pack_relu(acc2[par][d >> 1][t][2 * (d & 1)], acc2[par][d >> 1][t][2 * (d & 1) + 1]);
+        };
+#pragma unroll
+        for (int p = 0; p < kPairGroups; ++p) {
+            const int g = kPairBase + p;
+            const int kind = kPairOrder.kind[p], a = kPairOrder.a[p], b = kPairOrder.b[p];
+            const bf16x8 w = ws.take(g);
+            if (g == kPrefetchGroup)
+                ws.prefetch_mailbox(mailbox + (size_t)next_board * kMailboxBytes,
+                                    (unsigned)(uintptr_t)(lds_bytes)lds.next_mailbox[wave], lane);
+            // the shift of output tile b, two groups ahead of the first 512->128 group that starts from it
+            if (p >= 23 && p < 23 + 2 * kOutTiles && ((p - 23) & 1) == 0)
+                seed[(p - 23) >> 1] = *reinterpret_cast<const f32x4*>(&lds.bias2[16 * ((p - 23) >> 1) + 4 * q]);
+            if (kind == 0) {
+                const int par = (a >> 1) & 1;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const u32x4 x = u32x4{X[t][4 * b], X[t][4 * b + 1], X[t][4 * b + 2], X[t][4 * b + 3]};
+                    acc2[par][a & 1][t] = MFMA16(w, __builtin_bit_cast(bf16x8, x), b == 0 ? zero4() : acc2[par][a & 1][t]);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const u32x4 h = u32x4{H[t][0], H[t][1], H[t][2], H[t][3]};
+                    acc3[b][t] = MFMA16(w, __builtin_bit_cast(bf16x8, h), a == 0 ? seed[b] : acc3[b][t]);
+                }
+            }
+            // packs of pair h ride in the first eight groups of step h (the 236->512 groups of pair h + 1)
+            if (p >= 16 && p < 16 + 24 * 15) {
+                const int h = (p - 16) / 24, j = (p - 16) % 24;
+                if (j < 8) { pack_piece(h & 1, 2 * j); pack_piece(h & 1, 2 * j + 1); }
+            }
+            if (p == 16 + 24 * 15 - 1) {   // the last pair: packed in front of its own 512->128 groups
+#pragma unroll
+                for (int k = 0; k < 16; ++k) pack_piece(1, k);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (DBG) {
+#pragma unroll
+        for (int o = 0; o < kOutTiles; ++o)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dump_tile(dbg_board + 64 * (236 + 16 * o), q, 16 * t + c16, acc3[o][t]);
+    }
+
+    BF_STAMP(3);
+    // ---- stages 3 and 4: the six 3x3 layers through the wave's own planes ------------------------
+    // Flat list of 9 chunks x 36 slots: chunk c = 0..3 are the four 32-channel input chunks of the 128->32
+    // layer, c = 4..8 the five 32->32 layers; chunk c reads plane c & 1.  Slot = (column tile, tap): one
+    // shifted B read feeds the MFMAs of both output row tiles; column tile 0 takes the chunk's 18 fragments
+    // from the ring, tiles 1-3 reuse them from registers.  A layer's column tile t is written to the next
+    // plane a few slots after it finishes, i.e. while tile t + 1 multiplies; the next layer's tile t needs
+    // tiles t - 1 .. t + 1, the last of which was finished two tiles earlier.
+    auto write_tile = [&](int pl, int t, const f32x4& a0, const f32x4& a1) {
+        u32x4 v;
+        v.x = pack_relu(a0[0], a0[1]);
+        v.y = pack_relu(a0[2], a0[3]);
+        v.z = pack_relu(a1[0], a1[1]);
+        v.w = pack_relu(a1[2], a1[3]);
+        lds_order();
+        *reinterpret_cast<u32x4*>(region + pl * PLANE_BYTES + waddr + 2 * t * ROW_BYTES) = v;
+        lds_order();
+    };
+    auto load_b = [&](int n) -> u32x4 {
+        const int c = n / 36, t = (n % 36) / 9, tap = n % 9;
+        return *reinterpret_cast<const u32x4*>(region + (c & 1) * PLANE_BYTES + raddr[tap % 3] + (2 * t + tap / 3) * ROW_BYTES);
+    };
+#ifndef T16_CONV_D
+#define T16_CONV_D 6
+#endif
+    constexpr int D = T16_CONV_D, NSLOTS = 9 * 36;
+    static_assert(D <= 8, "a B read further ahead could pass the write of its input");
+    f32x4 A[2][2][4];   // [set][row tile][column tile]: chunks 0..3 accumulate in set 0, chunk c >= 4 in set c & 1 ^ 1 ... see `set`
+    f32x4 bs[2];        // shifts of the layer about to start, per row tile
+    u32x4 bq[D];
+    bf16x8 f[18];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) write_tile(0, t, acc3[0][t], acc3[1][t]);
+    bs[0] = *reinterpret_cast<const f32x4*>(&lds.bias3[4 * q]);
+    bs[1] = *reinterpret_cast<const f32x4*>(&lds.bias3[16 + 4 * q]);
+#pragma unroll
+    for (int n = 0; n < D; ++n) bq[n] = load_b(n);
+#pragma unroll
+    for (int n = 0; n < NSLOTS; ++n) {
+        const int c = n / 36, r = n % 36, t = r / 9, tap = r % 9;
+        if (n == 4 * 36) BF_STAMP(4);
+        const int set = c <= 3 ? 0 : ((c & 1) ^ 1);   // c = 4 -> 1, 5 -> 0, ...
+        if (t == 0) {
+            f[2 * tap] = ws.take(kConvBase + c * 18 + 2 * tap);
+            f[2 * tap + 1] = ws.take(kConvBase + c * 18 + 2 * tap + 1);
+        }
+        const bool fresh = tap == 0 && (c == 0 || c >= 4);
+        const bf16x8 bn = __builtin_bit_cast(bf16x8, bq[n % D]);
+        A[set][0][t] = MFMA16(f[2 * tap], bn, fresh ? bs[0] : A[set][0][t]);
+        A[set][1][t] = MFMA16(f[2 * tap + 1], bn, fresh ? bs[1] : A[set][1][t]);
+        if (n + D < NSLOTS) bq[n % D] = load_b(n + D);
+        if (c < 3) {
+            // input of chunk c + 1 into the other plane (chunk c - 1's reads of it were issued long ago)
+            if (r >= 1 && r <= 4) write_tile((c + 1) & 1, r - 1, acc3[2 * (c + 1)][r - 1], acc3[2 * (c + 1) + 1][r - 1]);
+        } else if (c < 8) {
+            // column tile tw of x(c+1) two slots after its last MFMA: tiles 0..2 inside this chunk ...
+            if (r == 11 || r == 20 || r == 29) write_tile((c + 1) & 1, r / 9 - 1, A[set][0][r / 9 - 1], A[set][1][r / 9 - 1]);
+            if (r == 30) {   // shifts of the next layer
+                bs[0] = *reinterpret_cast<const f32x4*>(&lds.bias3[32 * (c + 1 - 3) + 4 * q]);
+                bs[1] = *reinterpret_cast<const f32x4*>(&lds.bias3[32 * (c + 1 - 3) + 16 + 4 * q]);
+            }
+        }
+        if (c >= 4 && r == 2) {   // ... tile 3 of the previous chunk at the start of this one
+            const int ps = c == 4 ? 0 : (((c - 1) & 1) ^ 1);
+            write_tile(c & 1, 3, A[ps][0][3], A[ps][1][3]);
+        }
+        if (DBG && c >= 3 && c < 8 && r == 35) {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                dump_tile(dbg_board + 64 * (236 + 128 + 32 * (c - 3)), q, 16 * tt + c16, A[set][0][tt]);
+                dump_tile(dbg_board + 64 * (236 + 128 + 32 * (c - 3) + 16), q, 16 * tt + c16, A[set][1][tt]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    f32x4 (&x9)[2][4] = A[1];  // chunk 8: set 1; x9 before its ReLU
+
+    BF_STAMP(5);
+    // the walk's padding groups bring the ring and the look-ahead back to their start phase
+#pragma unroll
+    for (int g = kStreamGroups; g < kStreamWalkGroups; ++g) (void)ws.take(g);
+
+    // ---- stage 5: 8x8 valid conv (2048 -> 16) across the workgroup's boards, ReLU, logit ----------
+    if (MODE == 2) {
+        if (board_raw < n_boards) {
+            float* out = scores + (size_t)board * 2048;
+#pragma unroll
+            for (int tile = 0; tile < 2; ++tile)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        out[(16 * tile + 4 * r + q) * 64 + 16 * t + c16] = fmaxf(x9[tile][t][r], 0.0f);
+        }
+    } else {
+    lds_order();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) write_tile(1, t, x9[0][t], x9[1][t]);   // x9 -> plane 1
+    if (DBG) {
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            dump_tile(dbg_board + 64 * (236 + 128 + 32 * 5), q, 16 * tt + c16, x9[0][tt]);
+            dump_tile(dbg_board + 64 * (236 + 128 + 32 * 5 + 16), q, 16 * tt + c16, x9[1][tt]);
+        }
+    }
+    lds_barrier();   // every wave's x9 is in its plane 1 (LDS only: the ring's DMA stays in flight)
+    {
+        // out[board][co]: activations first (rows = boards, lane l reads board l & 15, chunk l >> 4), kernels
+        // second, read from the AGPRs they were loaded into (inline asm; see eval_bf16.hip)
+        const unsigned char* xb = lds.board[c16 < BPB ? c16 : 0] + PLANE_BYTES;
+        u32x4 hb[SQW], hk[SQW - SQR];
+#pragma unroll
+        for (int i = 0; i < SQW; ++i) {
+            const int sqk = wave * SQW + i;
+            const int Rk = (sqk >> 3) + 1, Fk = (sqk & 7) + 1;
+            hb[i] = *reinterpret_cast<const u32x4*>(xb + (Rk * XP_W + Fk) * POS_BYTES + (((q + Fk) & 3) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < SQW - SQR; ++i) hk[i] = lds.headk[wave][i][lane];
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 hacc = f32x4{0.f, 0.f, 0.f, 0.f};
+        // register half: inline asm so that the kernels are read from the AGPRs they live in (s_nop: an AGPR the
+        // compiler has just moved is not yet visible to an MFMA that hipcc does not know is one)
+        if (DBG) {
+            // the debug build spills registers: it reads the kernels again instead of trusting asm operands
+            const f32x4* hwp = headw + (size_t)wave * SQW * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < SQR; ++i)
+                hacc = MFMA16(__builtin_bit_cast(bf16x8, hb[i]), __builtin_bit_cast(bf16x8, hwp[i * 64]), hacc);
+        } else {
+#pragma unroll
+            for (int i = 0; i < SQR; ++i)
+                asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(hacc) : "v"(hb[i]), "a"(ha[i]));
+            asm volatile("s_nop 15\n\ts_nop 3" : "+v"(hacc));
+        }
+#pragma unroll
+        for (int i = SQR; i < SQW; ++i)
+            hacc = MFMA16(__builtin_bit_cast(bf16x8, hb[i]), __builtin_bit_cast(bf16x8, hk[i - SQR]), hacc);
+        lds.hpart[wave][lane] = hacc;
+    }
+    lds_barrier();
+    if (tid < 16 * BPB) {
+        const int b = tid >> 4, co = tid & 15;
+        // D[row = b][col = co] sits in lane co + 16*(b>>2), register b&3
+        float s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w)
+            s += reinterpret_cast<const float*>(lds.hpart[w])[(co + 16 * (b >> 2)) * 4 + (b & 3)];
+        const float y = fmaxf(s + head_shift, 0.0f);
+        const unsigned out_raw = quad * BPB + b;
+        if (DBG && out_raw < n_boards) dbg[(size_t)out_raw * kDebugFloatsPerBoard + 64 * (236 + 128 + 32 * 6) + co] = y;
+        float v = y * head_logit;  // logit_layer: no bias, no batch-norm (evaluation_ann.py:35-44)
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 8);
+        if (co == 0 && out_raw < n_boards) scores[out_raw] = v;
+    }
+    }
+    BF_STAMP(6);
+#ifdef BF_STAMPS
+    stamps[14] = (unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
+    }  // board loop
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring's look-ahead DMA must not outlive the workgroup
+#ifdef BF_STAMPS
+    if (!DBG && dbg && lane == 0) {
+        long long* out = reinterpret_cast<long long*>(dbg) + ((size_t)blockIdx.x * WAVES + wave) * 16;
+        for (int i = 0; i < 15; ++i) out[i] = (long long)stamps[i];
+    }
+#endif
+}
+
+hipError_t grid_blocks(size_t n, unsigned* blocks) {
+    static int cus[64] = {0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    int count = (dev >= 0 && dev < 64) ? cus[dev] : 0;
+    if (count == 0) {
+        e = hipDeviceGetAttribute(&count, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return e;
+        if (count <= 0) count = 256;
+        if (dev >= 0 && dev < 64) cus[dev] = count;
+    }
+    const size_t quads = (n + BPB - 1) / BPB;
+    *blocks = (unsigned)(quads < (size_t)count ? quads : (size_t)count);
+    return hipSuccess;
+}
+
+}  // namespace
+
+}  // namespace t16
+
+hipError_t launch_eval_t16(const uint8_t* d_mailbox, size_t n, const unsigned char* d_image, float* d_scores,
+                           float* d_debug, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const f32x4* ws = reinterpret_cast<const f32x4*>(d_image + t16::kOffStream);
+    const float* bias = reinterpret_cast<const float*>(d_image + t16::kOffBias);
+    const f32x4* head = reinterpret_cast<const f32x4*>(d_image + t16::kOffHead);
+    unsigned blocks = 0;
+    hipError_t e = t16::grid_blocks(n, &blocks);
+    if (e != hipSuccess) return e;
+#if defined(BF_STAMPS) || defined(T16_NO_DEBUG_KERNEL)
+    if (false)
+#else
+    if (d_debug)
+#endif
+        hipLaunchKernelGGL(t16::k_eval_t16<1>, dim3(blocks), dim3(t16::THREADS), 0, stream, d_mailbox, (unsigned)n, ws, bias, head,
+                           d_scores, d_debug);
+    else
+        hipLaunchKernelGGL(t16::k_eval_t16<0>, dim3(blocks), dim3(t16::THREADS), 0, stream, d_mailbox, (unsigned)n, ws, bias, head,
+                           d_scores, d_debug);
+    return hipGetLastError();
+}
+
+hipError_t launch_policy_features_t16(const uint8_t* d_mailbox, size_t n, const unsigned char* d_image, float* d_x9,
+                                      hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    unsigned blocks = 0;
+    hipError_t e = t16::grid_blocks(n, &blocks);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(t16::k_eval_t16<2>, dim3(blocks), dim3(t16::THREADS), 0, stream, d_mailbox, (unsigned)n,
+                       reinterpret_cast<const f32x4*>(d_image + t16::kOffStream),
+                       reinterpret_cast<const float*>(d_image + t16::kOffBias),
+                       reinterpret_cast<const f32x4*>(d_image + t16::kOffHead), d_x9, nullptr);
+    return hipGetLastError();
+}
+
+}  // namespace bf

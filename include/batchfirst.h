@@ -278,6 +278,11 @@ int bf_pack_policy_weights(const float* h_weights, size_t n_floats, float* h_pac
 size_t bf_packed_bf16_bytes(void);
 int bf_pack_weights_bf16(const float* h_weights, size_t n_floats, void* h_image, size_t n_bytes);
 
+/* The same for the image of the 16x16x32 bf16 kernel (batch_first_amd/csrc/bf_layout_t16.h), which is
+ * what a BF_PRECISION_BF16 context uploads; checked on a CPU by tests/kernel_sim_t16.py. */
+size_t bf_packed_t16_bytes(void);
+int bf_pack_weights_t16(const float* h_weights, size_t n_floats, void* h_image, size_t n_bytes);
+
 #ifdef __cplusplus
 }
 #endif

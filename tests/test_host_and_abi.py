@@ -120,3 +120,26 @@ def test_bf16_image_drives_kernel_model_to_bf16_oracle(golden):
     assert np.max(np.abs(scores - ref)) <= 1e-6
     rc = lib.bf_pack_weights_bf16(blob.ctypes.data, blob.size, image.ctypes.data, image.size - 1)
     assert rc == _lib.BF_E_ARG
+
+
+def test_t16_image_drives_kernel_model_to_bf16_oracle(golden):
+    """The image of the 16x16x32 bf16 kernel (bf_pack_weights_t16) walked lane by lane as eval_t16.hip walks
+    it (tests/kernel_sim_t16.py): every bf16 activation equals oracle.network.forward_bf16_model's, i.e. the
+    fragment order, the k permutations between layers, the tap pairing and tile skipping of stage 1 and the
+    plane channel order are what the packer and the kernel agree on."""
+    import kernel_sim_t16
+    lib = _lib.load()
+    w = W.make_weights(seed=1234, bn="perturbed")
+    blob = W.to_blob(w)
+    image = np.zeros(lib.bf_packed_t16_bytes(), np.uint8)
+    _lib.check(lib.bf_pack_weights_t16(blob.ctypes.data, blob.size, image.ctypes.data, image.size))
+    idx = [3, 777]
+    scores, inters, mfmas = kernel_sim_t16.eval_boards(image, golden["mailbox"][idx])
+    planes = E.decode_planes_fast(golden["piece_filters"], golden["occupied_bbs"])[idx]
+    ref, ri = N.forward_bf16_model(planes, w, return_intermediates=True, double=True)
+    for name in ("x1", "x3", "x4", "x5", "x9"):
+        got = np.stack([i[name] for i in inters])
+        assert np.array_equal(got, ri[name].reshape(got.shape)), name   # bf16 values: exact
+    assert np.max(np.abs(scores - ref)) <= 1e-6
+    assert mfmas == 2468    # 39 488 matrix-pipe cycles a board: DESIGN.md 3.2
+    assert lib.bf_pack_weights_t16(blob.ctypes.data, blob.size, image.ctypes.data, image.size - 1) == _lib.BF_E_ARG

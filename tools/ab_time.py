@@ -1,7 +1,7 @@
 """Interleaved A/B timing of k_eval_f32 across library builds, in one process (rule: perf deltas
 come from interleaved rounds on one device).
 
-    python tools/ab_time.py [--n 65536] [--rounds 7] name=path/to/lib.so ...
+    python tools/ab_time.py [--n 65536] [--rounds 7] name=path/to/lib.so[@VAR=value] ...
 
 Each library gets its own context with the same weights; every round launches each library's
 bf_eval_mailbox once, timed with events on torch's current stream.  Prints median/min ms and the
@@ -37,6 +37,11 @@ def main():
     libs = []
     for spec in args.libs:
         name, path = spec.split("=", 1)
+        env = {}
+        if "@" in path:     # name=lib.so@VAR=value: environment for the context's creation (e.g. BF_BF16_TILES=32)
+            path, rest = path.split("@", 1)
+            env = dict(kv.split("=", 1) for kv in rest.split("@"))
+        os.environ.update(env)
         lib = ctypes.CDLL(os.path.join(ROOT, path) if not os.path.isabs(path) else path)
         for fn, (res, argt) in _lib.SIGNATURES.items():
             if hasattr(lib, fn):
@@ -45,6 +50,8 @@ def main():
         ctx = ctypes.c_void_p()
         rc = lib.bf_ctx_create_ex(ctypes.byref(ctx), 0, blob.ctypes.data, blob.size, _lib.precision_code(args.dtype))
         assert rc == 0, lib.bf_last_error()
+        for k in env:
+            del os.environ[k]
         libs.append((name, lib, ctx))
     recs = torch.from_numpy(np.ascontiguousarray(positions.to_compact(structs)).view(np.uint8).reshape(args.n, -1).copy()).cuda()
     mailbox = torch.empty((args.n, 32), dtype=torch.uint8, device="cuda")
