@@ -46,18 +46,24 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int BPB = 4;                   // boards per workgroup = waves per workgroup
 constexpr int WAVES = BPB;
 constexpr int THREADS = 64 * WAVES;
-constexpr int CHUNK = 16;                // groups per lockstep chunk of the weight ring
+#ifndef T16_CHUNK
+#define T16_CHUNK 16
+#endif
+#ifndef T16_SLOTS
+#define T16_SLOTS 4
+#endif
+constexpr int CHUNK = T16_CHUNK;         // groups per lockstep chunk of the weight ring
 constexpr int SHARE = CHUNK / WAVES;     // groups each wave fetches per chunk
-constexpr int SLOTS = 4;                 // ring slots
+constexpr int SLOTS = T16_SLOTS;         // ring slots: one being read, one just read, SLOTS - 2 landed or in flight
 #ifndef T16_LA
-#define T16_LA 7
+#define T16_LA 3
 #endif
 constexpr int LA = T16_LA;               // groups held in registers ahead of the MFMAs
 constexpr int AHEAD = SLOTS - 2;         // chunks the refill runs ahead of the chunk being read
 constexpr int WALK_CHUNKS = kStreamWalkGroups / CHUNK;
 static_assert(kStreamWalkGroups % CHUNK == 0 && WALK_CHUNKS % SLOTS == 0 && kStreamWalkGroups % (LA + 1) == 0,
               "every board starts in the same phase of the ring and of the register look-ahead");
-static_assert(SHARE == 4, "fetch_piece: four pieces with immediate offsets");
+static_assert(SHARE >= 1 && SHARE <= 4 && CHUNK % WAVES == 0 && LA <= CHUNK, "fetch_piece: up to four pieces with immediate offsets");
 
 constexpr int MB_W = 22;                 // byte mailbox padded by 7 squares on every side
 constexpr int MB_WORDS = 124;
@@ -86,7 +92,11 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 template <int EXTRA>
 __device__ __forceinline__ void ring_barrier() {
     constexpr int N = (AHEAD - 1) * SHARE + EXTRA;
+#ifdef T16_ABL_NOBAR   // timing ablation: waves do not wait for each other (wrong scores)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#else
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+#endif
 }
 
 // The next board's mailbox is prefetched after the take of this group (the take that issues the last piece
@@ -122,6 +132,9 @@ struct WStream {
         sbase = reinterpret_cast<const unsigned char*>((uintptr_t)(((unsigned long long)hi << 32) | lo));
     }
     __device__ __forceinline__ void fetch_piece(int i) {
+#ifdef T16_ABL_NODMA   // timing ablation: no weight DMA (stale ring contents, wrong scores)
+        return;
+#endif
         if (i == 0) asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase) : "memory");
         if (i == 1) asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" ::"v"(voff), "s"(sbase) : "memory");
         if (i == 2) asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" ::"v"(voff), "s"(sbase) : "memory");
@@ -292,7 +305,16 @@ static_assert(kS1.n <= kMaxUnits && kS1.ntail <= 64 && s1_jobs_meet_deadlines(),
 __device__ __forceinline__ unsigned s1_pack(int t, int d, const f32x4 (&acc)[2][4][4]) {
     const X1Slot a = x1_slot(2 * d), b = x1_slot(2 * d + 1);
     unsigned p = pack_relu(acc[a.conv & 1][a.tile][t][a.r], acc[b.conv & 1][b.tile][t][b.r]);
-    asm volatile("" : "+v"(p));   // pinned where it is scheduled (see eval_bf16.hip: the compiler sinks unpinned packs)
+    // pinned where it is scheduled (see eval_bf16.hip: the compiler sinks unpinned packs), and pinned INTO THE
+    // ACCUMULATOR FILE: x1 is only ever a B operand, which an MFMA reads from an AGPR directly; left to the
+    // allocator it stays in the 256 architectural VGPRs, where stage 2's 192 accumulator registers then no
+    // longer fit, and the 512->128 accumulators get copied in and out of AGPRs around their MFMAs (730 copy
+    // instructions and 700 cycles of hazard nops per board in the first build)
+#ifndef T16_X_IN_VGPR
+    asm volatile("" : "+a"(p));
+#else
+    asm volatile("" : "+v"(p));
+#endif
     return p;
 }
 

@@ -32,7 +32,9 @@ PEAK_HBM_GBS = 8000.0
 # under profiles/ (FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes; see
 # tools/pmc_summary.py).  Counters cannot be read from inside this process, so the figure is the
 # committed measurement of the same kernel and batch, not a live one.
-TRAFFIC_PROFILES = {"f32": "profiles/r1/pmc_k_eval_f32_v8.json", "bf16": "profiles/r1/pmc_k_eval_bf16_v8.json"}
+TRAFFIC_PROFILES = {"f32": "profiles/r2/pmc_k_eval_f32_r2b.json", "bf16": "profiles/r2/pmc_k_eval_t16_r2b.json"}
+# the bf16 kernel the library launches: the 16x16x32 one unless BF_BF16_TILES=32 selects its predecessor
+BF16_KERNEL = "k_eval_bf16" if os.environ.get("BF_BF16_TILES") == "32" else "k_eval_t16"
 
 
 def profiled_traffic(dtype):
@@ -191,7 +193,7 @@ def main():
         other = {"value": total_boards * args.steps / o_elapsed, "unit": "boards/s", "steps": args.steps, "warmup": args.warmup,
                  "ms_per_step": 1e3 * o_elapsed / args.steps, "dtype": "bf16",
                  "config": {"workload": "BASELINE configs[2] kernel (bf16 operands, fp32 sums) on the headline's records and batch"},
-                 "roofline": {"bound": "mfma", "kernel": "k_eval_bf16", "achieved": o_tflops, "peak": PEAK_BF16_MFMA_TFLOPS,
+                 "roofline": {"bound": "mfma", "kernel": BF16_KERNEL, "achieved": o_tflops, "peak": PEAK_BF16_MFMA_TFLOPS,
                               "unit": "TFLOP/s", "frac": o_tflops / PEAK_BF16_MFMA_TFLOPS, "kernel_ms": o_kernel_ms,
                               "traffic": o_traffic, "traffic_source": o_src, "flops_per_board": spec.FLOPS_PER_BOARD}}
         o_ctx.close()
@@ -257,7 +259,7 @@ def main():
                        "per_gpu_batch": ((1 << 24) // world) if shard else n,
                        "global_batch": total_boards,
                        "parallelism": "independent shards per GPU" + (", RCCL gather of scores to rank 0" if world > 1 else "")},
-            "roofline": {"bound": "mfma", "kernel": "k_eval_bf16" if bf16 else "k_eval_f32", "achieved": achieved_tflops,
+            "roofline": {"bound": "mfma", "kernel": BF16_KERNEL if bf16 else "k_eval_f32", "achieved": achieved_tflops,
                          "peak": peak_tflops, "unit": "TFLOP/s", "frac": achieved_tflops / peak_tflops,
                          "traffic": traffic, "traffic_unit": "bytes per launch (HBM, PMC)", "traffic_source": traffic_src,
                          "algorithmic_bytes": n * (32 + 4), "kernel_ms": kernel_ms,

@@ -10,5 +10,5 @@ timeout -s KILL 90 rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$out/p4" -
 timeout -s KILL 90 rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$out/p5" -- $B > "$out/p5.log" 2>&1
 timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 bench.py --dtype bf16 --steps 20 --warmup 3 --no-cpu-baseline > "$out/stats.log" 2>&1
 cp "$out"/stats/*/*_kernel_stats.csv "$out/kernel_stats_bf16.csv"
-python3 tools/pmc_summary.py k_eval_bf16 "$out/pmc_k_eval_bf16.json" "$out/p1" "$out/p2" "$out/p3" "$out/p4" "$out/p5"
+python3 tools/pmc_summary.py ${BF16_KERNEL:-k_eval_t16} "$out/pmc_${BF16_KERNEL:-k_eval_t16}.json" "$out/p1" "$out/p2" "$out/p3" "$out/p4" "$out/p5"
 rm -rf "$out/p1" "$out/p2" "$out/p3" "$out/p4" "$out/p5" "$out/stats"
