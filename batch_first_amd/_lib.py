@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# BATCHFIRST_LIB: another build of the same library (A/B timing and diagnostics, tools/build_t16_variant.sh)
+# BATCHFIRST_LIB: another build of the same library (A/B timing and diagnostics, tools/build_variant.sh)
 LIB_PATH = os.environ.get("BATCHFIRST_LIB") or os.path.join(_HERE, "libbatchfirst_hip.so")
 
 BF_OK, BF_E_ARG, BF_E_HIP, BF_E_FORMAT, BF_E_NOGPU = 0, -1, -2, -3, -4

@@ -25,6 +25,7 @@
 // :199) can have one call of each in flight at the same time.
 struct Lane {
     int* d_err = nullptr;            // sticky malformed-input flag
+    int* h_flag = nullptr;           // pinned landing place of its copy (a pageable one would cost a staged copy per call)
     // scratch grown on demand; guarded by `mu` (calls on one lane are serialised)
     std::mutex mu;
     size_t cap_boards = 0;
@@ -45,6 +46,11 @@ struct Lane {
     size_t cap_scores = 0;
     float* h_scores = nullptr;       // pinned
     float* d_scores = nullptr;
+    // Small calls skip the copy engine: the kernels read the pinned staging and write the pinned scores over
+    // the bus themselves (a copy costs 5-8 us of queueing each way, more than moving a few KB): the device's
+    // addresses of h_in / h_scores.  The search's batches at depth 4 are a hundred boards (profiles/r2/search).
+    unsigned char* h_in_dev = nullptr;
+    float* h_scores_dev = nullptr;
 };
 
 struct bf_ctx : Lane {               // the base is the value network's lane
@@ -63,6 +69,8 @@ struct bf_ctx : Lane {               // the base is the value network's lane
     size_t cap_x9_boards = 0;
     float* d_x9 = nullptr;                // [boards][32][64] features of the batch in flight
     size_t policy_boards = 0;             // boards of the started, not yet finished, prediction
+    bool policy_no_flags = false;         // the started prediction came from records (no device-side format checks)
+    size_t policy_in_used = 0;            // bytes of the policy lane's staging that the started prediction's records occupy
     bool policy_started = false;
 };
 
@@ -104,6 +112,11 @@ int ensure_staging(Lane* c, size_t in_bytes, size_t n_scores) {
         c->h_in = nullptr; c->d_in = nullptr; c->cap_in_bytes = 0;
         BF_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_in), cap, hipHostMallocDefault));
         BF_HIP(hipMalloc(&c->d_in, cap));
+        c->h_in_dev = nullptr;
+        if (hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_in_dev), c->h_in, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            c->h_in_dev = nullptr;   // not mapped: every call goes through the copies
+        }
         c->cap_in_bytes = cap;
     }
     if (n_scores > c->cap_scores) {
@@ -114,6 +127,11 @@ int ensure_staging(Lane* c, size_t in_bytes, size_t n_scores) {
         c->h_scores = nullptr; c->d_scores = nullptr; c->cap_scores = 0;
         BF_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_scores), cap * sizeof(float), hipHostMallocDefault));
         BF_HIP(hipMalloc(&c->d_scores, cap * sizeof(float)));
+        c->h_scores_dev = nullptr;
+        if (hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_scores_dev), c->h_scores, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            c->h_scores_dev = nullptr;
+        }
         c->cap_scores = cap;
     }
     return BF_OK;
@@ -142,9 +160,11 @@ int scratch_release(Lane* c, hipStream_t s) {
 }
 
 int read_err_flag(Lane* c, hipStream_t s) {
-    int flag = 0;
-    BF_HIP(hipMemcpyAsync(&flag, c->d_err, sizeof flag, hipMemcpyDeviceToHost, s));
+    if (!c->h_flag) BF_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_flag), 64, hipHostMallocDefault));
+    *c->h_flag = 0;
+    BF_HIP(hipMemcpyAsync(c->h_flag, c->d_err, sizeof(int), hipMemcpyDeviceToHost, s));
     BF_HIP(hipStreamSynchronize(s));
+    const int flag = *c->h_flag;
     if (flag) {
         BF_HIP(hipMemsetAsync(c->d_err, 0, sizeof(int), s));
         BF_HIP(hipStreamSynchronize(s));
@@ -156,6 +176,16 @@ int read_err_flag(Lane* c, hipStream_t s) {
 }
 
 constexpr size_t kMaxBoards = (size_t)1 << 26;
+// calls of at most this many boards / moves use the direct path (Lane::h_in_dev); BF_DIRECT_BOARDS=0 turns it off
+size_t direct_boards() {
+    static const size_t v = [] {
+        const char* e = std::getenv("BF_DIRECT_BOARDS");
+        return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)2048;
+    }();
+    return v;
+}
+constexpr size_t kDirectMovesPerBoard = 64;
+constexpr size_t kPolicyMoveRoom = 64;   // moves a board that bf_policy_start_structs_host reserves staging for
 
 // ---- scratch of the allocation-free entry point (bf_eval_structs_noalloc) -----------------------
 // The mailboxes of one call, uint8 [BF_NOALLOC_MAX_BOARDS][32] = 8 MiB, in a file-scope device array:
@@ -266,6 +296,7 @@ extern "C" void bf_ctx_destroy(bf_ctx* c) {
         }
         if (lane->scratch_done) (void)hipEventDestroy(lane->scratch_done);
         if (lane->d_err) (void)hipFree(lane->d_err);
+        if (lane->h_flag) (void)hipHostFree(lane->h_flag);
         if (lane->d_local_off) (void)hipFree(lane->d_local_off);
         if (lane->d_block_total) (void)hipFree(lane->d_block_total);
         if (lane->d_mailbox) (void)hipFree(lane->d_mailbox);
@@ -469,12 +500,13 @@ extern "C" int bf_eval_structs_host(bf_ctx* c, const void* h_structs, size_t str
         std::memcpy(c->h_in + k * kCompact, recs + j * stride, BF_NODE_EVAL_BYTES);
         ++k;
     }
+    const bool direct = m <= direct_boards() && c->h_in_dev && c->h_scores_dev;
     if (int r = scratch_acquire(c, c->stream)) return r;
-    BF_HIP(hipMemcpyAsync(c->d_in, c->h_in, m * kCompact, hipMemcpyHostToDevice, c->stream));
-    BF_HIP(bf::launch_mailbox_from_structs(c->d_in, kCompact, m, c->d_mailbox, c->stream));
-    BF_HIP(launch_eval(c, c->d_mailbox, m, c->d_scores, nullptr, c->stream));
+    if (!direct) BF_HIP(hipMemcpyAsync(c->d_in, c->h_in, m * kCompact, hipMemcpyHostToDevice, c->stream));
+    BF_HIP(bf::launch_mailbox_from_structs(direct ? c->h_in_dev : c->d_in, kCompact, m, c->d_mailbox, c->stream));
+    BF_HIP(launch_eval(c, c->d_mailbox, m, direct ? c->h_scores_dev : c->d_scores, nullptr, c->stream));
     if (int r = scratch_release(c, c->stream)) return r;
-    BF_HIP(hipMemcpyAsync(c->h_scores, c->d_scores, m * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (!direct) BF_HIP(hipMemcpyAsync(c->h_scores, c->d_scores, m * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     BF_HIP(hipStreamSynchronize(c->stream));
     std::memcpy(h_scores, c->h_scores, m * sizeof(float));
     if (n_scored) *n_scored = m;
@@ -789,6 +821,8 @@ extern "C" int bf_policy_start_wire_host(bf_ctx* c, const uint8_t* h_pf, size_t 
                                             workspace(L), L->d_mailbox, L->stream));
         BF_HIP(launch_policy_features(c, L->d_mailbox, n, c->d_x9, L->stream));
         if (int r = scratch_release(L, L->stream)) return r;
+        c->policy_in_used = (pf_off + n_bytes + 255) & ~(size_t)255;
+        c->policy_no_flags = false;  // the wire decoder reports malformed input through the flag
     }
     c->policy_boards = n;
     c->policy_started = true;
@@ -814,7 +848,10 @@ extern "C" int bf_policy_start_structs_host(bf_ctx* c, const void* h_structs, si
         BF_HIP(hipStreamSynchronize(L->stream));
         if (int r = ensure_boards(L, m)) return r;
         if (int r = ensure_x9(c, m)) return r;
-        if (int r = ensure_staging(L, m * kCompact, 1)) return r;
+        // room behind the records for stage 2's move lists (kPolicyMoveRoom moves a board), so that
+        // bf_policy_finish_host can stage them while stage 1 still reads the records
+        const size_t rec_bytes = (m * kCompact + 255) & ~(size_t)255;
+        if (int r = ensure_staging(L, rec_bytes + m * kPolicyMoveRoom * 6 + 64, m * kPolicyMoveRoom)) return r;
         const unsigned char* recs = static_cast<const unsigned char*>(h_structs);
         size_t k = 0;
         for (size_t j = 0; j < n; ++j) {
@@ -822,11 +859,14 @@ extern "C" int bf_policy_start_structs_host(bf_ctx* c, const void* h_structs, si
             std::memcpy(L->h_in + k * kCompact, recs + j * stride, BF_NODE_EVAL_BYTES);
             ++k;
         }
+        const bool direct = m <= direct_boards() && L->h_in_dev;
         if (int r = scratch_acquire(L, L->stream)) return r;
-        BF_HIP(hipMemcpyAsync(L->d_in, L->h_in, m * kCompact, hipMemcpyHostToDevice, L->stream));
-        BF_HIP(bf::launch_mailbox_from_structs(L->d_in, kCompact, m, L->d_mailbox, L->stream));
+        if (!direct) BF_HIP(hipMemcpyAsync(L->d_in, L->h_in, m * kCompact, hipMemcpyHostToDevice, L->stream));
+        BF_HIP(bf::launch_mailbox_from_structs(direct ? L->h_in_dev : L->d_in, kCompact, m, L->d_mailbox, L->stream));
         BF_HIP(launch_policy_features(c, L->d_mailbox, m, c->d_x9, L->stream));
         if (int r = scratch_release(L, L->stream)) return r;
+        c->policy_in_used = rec_bytes;
+        c->policy_no_flags = true;   // nothing in this prediction's first stage can raise the device's error flag
     }
     c->policy_boards = m;
     c->policy_started = true;
@@ -860,20 +900,34 @@ extern "C" int bf_policy_finish_host(bf_ctx* c, const uint8_t* h_from, const uin
     // board index as numpy_style_repeat_1d_creator does on the device (ann_creation_helper.py:488-510)
     const size_t from_off = n_moves * sizeof(uint32_t), filter_off = from_off + ((n_moves + 15) & ~(size_t)15);
     const size_t bytes = filter_off + n_moves;
-    BF_HIP(hipStreamSynchronize(L->stream));   // stage 1 has read the staging buffer
-    if (int r = ensure_staging(L, bytes + 16, n_moves)) return r;
-    uint32_t* idx = reinterpret_cast<uint32_t*>(L->h_in);
+    // The move lists go behind the records that stage 1 may still be reading; only when the room reserved
+    // there (or the scores buffer) is too small is stage 1 drained and the staging regrown.
+    size_t base = c->policy_in_used;
+    if (base + bytes + 16 > L->cap_in_bytes || n_moves > L->cap_scores) {
+        BF_HIP(hipStreamSynchronize(L->stream));
+        if (int r = ensure_staging(L, bytes + 16, n_moves)) return r;
+        base = 0;
+    }
+    uint32_t* idx = reinterpret_cast<uint32_t*>(L->h_in + base);
     size_t m = 0;
     for (size_t b = 0; b < n_boards; ++b)
         for (unsigned k = 0; k < h_moves_per_board[b]; ++k) idx[m++] = (uint32_t)b;
-    std::memcpy(L->h_in + from_off, h_from, n_moves);
-    std::memcpy(L->h_in + filter_off, h_filter, n_moves);
-    BF_HIP(hipMemcpyAsync(L->d_in, L->h_in, bytes, hipMemcpyHostToDevice, L->stream));
-    BF_HIP(bf::launch_policy_scores(c->d_x9, policy_logit_w(c), reinterpret_cast<const unsigned*>(L->d_in),
-                                    L->d_in + from_off, L->d_in + filter_off, n_moves, n_boards, L->d_err, L->d_scores,
+    std::memcpy(L->h_in + base + from_off, h_from, n_moves);
+    std::memcpy(L->h_in + base + filter_off, h_filter, n_moves);
+    // from-squares, filters and the per-board counts were checked above and the board index is made here, so
+    // the kernel's range checks cannot fire: the direct path reads the flag only after a wire-format first stage
+    const bool direct = n_moves <= direct_boards() * kDirectMovesPerBoard && L->h_in_dev && L->h_scores_dev;
+    const unsigned char* src = direct ? L->h_in_dev + base : L->d_in + base;
+    if (!direct) BF_HIP(hipMemcpyAsync(L->d_in + base, L->h_in + base, bytes, hipMemcpyHostToDevice, L->stream));
+    BF_HIP(bf::launch_policy_scores(c->d_x9, policy_logit_w(c), reinterpret_cast<const unsigned*>(src), src + from_off,
+                                    src + filter_off, n_moves, n_boards, L->d_err, direct ? L->h_scores_dev : L->d_scores,
                                     L->stream));
-    BF_HIP(hipMemcpyAsync(L->h_scores, L->d_scores, n_moves * sizeof(float), hipMemcpyDeviceToHost, L->stream));
-    if (int r = read_err_flag(L, L->stream)) return r;
+    if (!direct) BF_HIP(hipMemcpyAsync(L->h_scores, L->d_scores, n_moves * sizeof(float), hipMemcpyDeviceToHost, L->stream));
+    if (direct && c->policy_no_flags) {
+        BF_HIP(hipStreamSynchronize(L->stream));
+    } else if (int r = read_err_flag(L, L->stream)) {
+        return r;
+    }
     std::memcpy(h_scores, L->h_scores, n_moves * sizeof(float));
     return BF_OK;
 }

@@ -6,15 +6,17 @@
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "board.h"
+#include "threads.h"
 
 using namespace bfs;
 
@@ -86,6 +88,7 @@ struct TTEntry {
 };
 
 struct Node {
+    Node() {}   // deliberately empty: growing the arena must not zero 800 bytes a node; iterate() sets every field it reads
     Board b;
     int parent;
     float separator, best_value;
@@ -97,6 +100,31 @@ struct Node {
     float move_scores[kMaxMoves];
 };
 
+// The node arena: fixed blocks, so that growing never copies or zeroes what is there (a std::vector of 800-byte
+// nodes spent a sixth of the search re-allocating), and an index stays valid for the whole search.
+class Arena {
+public:
+    static constexpr size_t kShift = 14, kBlock = (size_t)1 << kShift;   // 16 384 nodes = 13 MiB a block
+    Arena() = default;
+    Arena(const Arena&) = delete;
+    Arena& operator=(const Arena&) = delete;
+    ~Arena() {
+        for (Node* b : blocks_) ::operator delete(b);
+    }
+    size_t size() const { return size_; }
+    Node& operator[](size_t i) { return blocks_[i >> kShift][i & (kBlock - 1)]; }
+    const Node& operator[](size_t i) const { return blocks_[i >> kShift][i & (kBlock - 1)]; }
+    void clear() { size_ = 0; }        // blocks are kept for the next search
+    void resize(size_t n) {            // may throw std::bad_alloc; new nodes are uninitialised
+        while (blocks_.size() * kBlock < n) blocks_.push_back(static_cast<Node*>(::operator new(kBlock * sizeof(Node))));
+        size_ = n;
+    }
+
+private:
+    std::vector<Node*> blocks_;
+    size_t size_ = 0;
+};
+
 double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 }  // namespace
@@ -106,11 +134,24 @@ struct bfs_search {
     std::vector<float> bins_desc;
     std::vector<TTEntry> tt;
     u64 tt_mask = 0;
-    std::vector<Node> nodes;
+    Arena nodes;
     std::vector<std::vector<int>> bins;
     size_t in_bins = 0;
     bfs_stats stats{};
     std::string error;
+    size_t max_nodes = (size_t)1 << 24;
+    std::unique_ptr<Pool> pool;      // per-node loops of a batch
+    std::unique_ptr<Lane> eval_lane; // value-network calls, beside the host work on the other children
+    // buffers of iterate(), kept between calls
+    std::vector<float> parent_next_score, eval_scores, move_scores_buf;
+    std::vector<uint8_t> flags, mv_from, mv_filt, mv_per;
+    std::vector<int> to_eval, kept;
+    std::vector<Node*> to_score;
+    std::vector<Node> fresh;         // the children of the batch in flight; the ones that stay open move to the arena
+    std::vector<float> first_score;  // of the nodes score_moves() handled: the score of their best move
+    std::vector<size_t> move_base;
+    std::vector<EvalRecord> recs, policy_recs;
+    static constexpr size_t kGrain = 64;   // nodes per piece of a parallel loop
 
     // ---- transposition table (transposition_table.py) ------------------------------------
     TTEntry& entry(u64 h) { return tt[h & tt_mask]; }
@@ -289,43 +330,65 @@ struct bfs_search {
             }
     }
 
-    // Scores the moves of the listed nodes with the move-scoring network (start_move_scoring
-    // :164-180, get_move_from_and_filter_squares_and_sizes :485-527) or with the reference's fake.
-    int score_moves(const std::vector<Node*>& who, double* wait) {
+    // Scores the moves of the listed nodes with the move-scoring network (start_move_scoring :164-180,
+    // get_move_from_and_filter_squares_and_sizes :485-527) or with the reference's fake, puts a legal table move
+    // first and picks each node's first move (first_score[i]).
+    int score_moves(const std::vector<Node*>& who) {
         if (who.empty()) return 0;
+        move_base.resize(who.size() + 1);
         size_t total = 0;
-        for (Node* n : who) total += n->n_moves;
-        std::vector<float> scores(total);
+        for (size_t i = 0; i < who.size(); ++i) {
+            move_base[i] = total;
+            total += who[i]->n_moves;
+        }
+        move_base[who.size()] = total;
+        move_scores_buf.resize(total);
+        first_score.resize(who.size());
+        float* scores = move_scores_buf.data();
         if (cfg.move_start && cfg.move_finish) {
-            std::vector<EvalRecord> recs(who.size());
-            std::vector<uint8_t> from(total), filt(total), per(who.size());
-            size_t m = 0;
-            for (size_t i = 0; i < who.size(); ++i) {
-                const Node& n = *who[i];
-                to_record(n.b, &recs[i]);
-                per[i] = n.n_moves;
-                const int flip = n.b.turn ? 0 : 56;  // SQUARES_180 for black: the mover's frame
-                for (int k = 0; k < n.n_moves; ++k, ++m) {
-                    const int f = n.moves[k].from ^ flip, t = n.moves[k].to ^ flip;
-                    from[m] = (uint8_t)f;
-                    filt[m] = g_filter[f][t][n.moves[k].promo < 6 ? n.moves[k].promo : 0];
-                }
-            }
-            const double t0 = now();
-            if (cfg.move_start(cfg.move_user, recs.data(), sizeof(EvalRecord), nullptr, recs.size()))
+            policy_recs.resize(who.size());
+            mv_from.resize(total);
+            mv_filt.resize(total);
+            mv_per.resize(who.size());
+            // stage 1 is started on the records alone; the move lists are packed while the GPU runs it
+            pool->for_range(who.size(), 4 * kGrain, [&](size_t b, size_t e) {
+                for (size_t i = b; i < e; ++i) to_record(who[i]->b, &policy_recs[i]);
+            });
+            ++stats.policy_calls;
+            double tw = now();
+            if (cfg.move_start(cfg.move_user, policy_recs.data(), sizeof(EvalRecord), nullptr, policy_recs.size()))
                 return fail("the move-scoring network's start call failed");
-            if (cfg.move_finish(cfg.move_user, from.data(), filt.data(), per.data(), per.size(), total, scores.data()))
+            stats.eval_wait_seconds += now() - tw;
+            pool->for_range(who.size(), kGrain, [&](size_t b, size_t e) {
+                for (size_t i = b; i < e; ++i) {
+                    const Node& n = *who[i];
+                    mv_per[i] = n.n_moves;
+                    const int flip = n.b.turn ? 0 : 56;  // SQUARES_180 for black: the mover's frame
+                    size_t m = move_base[i];
+                    for (int k = 0; k < n.n_moves; ++k, ++m) {
+                        const int f = n.moves[k].from ^ flip, t = n.moves[k].to ^ flip;
+                        mv_from[m] = (uint8_t)f;
+                        mv_filt[m] = g_filter[f][t][n.moves[k].promo < 6 ? n.moves[k].promo : 0];
+                    }
+                }
+            });
+            tw = now();
+            if (cfg.move_finish(cfg.move_user, mv_from.data(), mv_filt.data(), mv_per.data(), mv_per.size(), total, scores))
                 return fail("the move-scoring network's finish call failed");
-            *wait += now() - t0;
+            stats.eval_wait_seconds += now() - tw;
         } else {
             for (size_t i = 0; i < total; ++i) scores[i] = total > 1 ? (float)((double)i / (double)(total - 1)) : 0.0f;
         }
         stats.moves_scored += total;
-        size_t m = 0;
-        for (Node* n : who) {
-            for (int k = 0; k < n->n_moves; ++k) n->move_scores[k] = scores[m++];
-            apply_tt_move(*n);
-        }
+        pool->for_range(who.size(), kGrain, [&](size_t b, size_t e) {
+            for (size_t i = b; i < e; ++i) {
+                Node& n = *who[i];
+                const float* src = scores + move_base[i];
+                for (int k = 0; k < n.n_moves; ++k) n.move_scores[k] = src[k];
+                apply_tt_move(n);
+                first_score[i] = next_best_move(n);   // the node is ready for the open list
+            }
+        });
         return 0;
     }
 
@@ -377,74 +440,95 @@ struct bfs_search {
     }
 
     // ---- one batch (do_iteration, :572-693) ------------------------------------------------
+    struct EvalCall {
+        bfs_search* s;
+        size_t n;
+    };
+    static int run_eval(void* arg) {
+        EvalCall* c = static_cast<EvalCall*>(arg);
+        size_t done = 0;
+        const int rc = c->s->cfg.board_eval(c->s->cfg.eval_user, c->s->recs.data(), sizeof(EvalRecord), nullptr, c->n,
+                                            c->s->eval_scores.data(), &done);
+        return rc ? rc : (done != c->n ? -1 : 0);
+    }
+
+    // The per-node loops run on the pool; everything that orders nodes (which boards go to the evaluators and
+    // in which order, tree and table updates, the open list) stays on the calling thread and walks the batch
+    // in index order, so a search does the same thing whatever the number of threads.
     int iterate(const std::vector<int>& batch, std::vector<int>* to_insert, std::vector<float>* insert_scores) {
         ++stats.iterations;
         const size_t n = batch.size();
-        std::vector<float> parent_next_score(n);
-        // children are built at the end of the arena; the ones that stay open remain there
-        const size_t first_child = nodes.size();
-        nodes.resize(first_child + n);
-        for (size_t j = 0; j < n; ++j) {
-            Node& p = nodes[batch[j]];
-            Node& c = nodes[first_child + j];
-            const Move m = p.moves[p.next_move_index];
-            parent_next_score[j] = next_best_move(p);
-            c.b = p.b;
-            push(c.b, m);
-            c.parent = batch[j];
-            c.separator = -p.separator;
-            c.best_value = FMIN;
-            c.depth = (uint8_t)(p.depth - 1);
-            c.terminated = false;
-            c.n_moves = 0;
-            c.next_move_index = kNoMoreMoves;
-            c.children_left = 0;
-            c.prev_move = m;
-        }
+        double t0 = now(), t1;
+        parent_next_score.resize(n);
+        flags.resize(n);
+        // Children are made in a block of their own that every batch reuses (it stays in cache); most of them end
+        // at birth (depth 0, draws, table hits, mates), and only the ones that stay open are copied to the end of
+        // the arena afterwards: the arena holds live nodes only and nothing in it ever moves.
+        if (fresh.size() < n) fresh.resize(n);
         // depth-zero children first, so that the evaluator gets its boards as early as possible
-        std::vector<int> to_eval;
-        std::vector<EvalRecord> recs;
-        for (size_t j = 0; j < n; ++j) {
-            Node& c = nodes[first_child + j];
-            if (c.depth == 0 && settle(c)) {
-                to_eval.push_back((int)j);
-                recs.emplace_back();
-                to_record(c.b, &recs.back());
+        pool->for_range(n, kGrain, [&](size_t b, size_t e) {
+            for (size_t j = b; j < e; ++j) {
+                Node& p = nodes[batch[j]];
+                Node& c = fresh[j];
+                const Move m = p.moves[p.next_move_index];
+                parent_next_score[j] = next_best_move(p);
+                c.b = p.b;
+                push(c.b, m);
+                c.parent = batch[j];
+                c.separator = -p.separator;
+                c.best_value = FMIN;
+                c.depth = (uint8_t)(p.depth - 1);
+                c.terminated = false;
+                c.n_moves = 0;
+                c.next_move_index = kNoMoreMoves;
+                c.children_left = 0;
+                c.prev_move = m;
+                flags[j] = (c.depth == 0 && settle(c)) ? 1 : 0;
             }
-        }
-        std::vector<float> eval_scores(to_eval.size());
-        std::thread eval_thread;
-        int eval_rc = 0;
+        });
+        to_eval.clear();
+        for (size_t j = 0; j < n; ++j)
+            if (flags[j]) to_eval.push_back((int)j);
+        EvalCall call{this, to_eval.size()};
         if (!to_eval.empty()) {
-            stats.boards_evaluated += to_eval.size();
-            stats.max_batch = std::max<uint64_t>(stats.max_batch, to_eval.size());
-            eval_thread = std::thread([&] {
-                size_t done = 0;
-                eval_rc = cfg.board_eval(cfg.eval_user, recs.data(), sizeof(EvalRecord), nullptr, recs.size(),
-                                         eval_scores.data(), &done);
-                if (!eval_rc && done != recs.size()) eval_rc = -1;
+            recs.resize(to_eval.size());
+            eval_scores.resize(to_eval.size());
+            pool->for_range(to_eval.size(), 4 * kGrain, [&](size_t b, size_t e) {
+                for (size_t k = b; k < e; ++k) to_record(fresh[to_eval[k]].b, &recs[k]);
             });
+            stats.boards_evaluated += to_eval.size();
+            ++stats.eval_calls;
+            stats.max_batch = std::max<uint64_t>(stats.max_batch, to_eval.size());
+            eval_lane->submit(&run_eval, &call);
         }
+        t1 = now(); stats.expand_seconds += t1 - t0; t0 = t1;
         // meanwhile: the other children (draws, table hits, mates, move generation) and their move scores
-        std::vector<Node*> to_score;
-        for (size_t j = 0; j < n; ++j) {
-            Node& c = nodes[first_child + j];
-            if (c.depth != 0 && settle(c)) to_score.push_back(&c);
-        }
-        double wait = 0;
-        const int score_rc = score_moves(to_score, &wait);
-        if (eval_thread.joinable()) {
-            const double t0 = now();
-            eval_thread.join();
-            wait += now() - t0;
-        }
-        stats.eval_wait_seconds += wait;
+        pool->for_range(n, kGrain, [&](size_t b, size_t e) {
+            for (size_t j = b; j < e; ++j) {
+                Node& c = fresh[j];
+                if (c.depth != 0) flags[j] = settle(c) ? 2 : 0;
+            }
+        });
+        to_score.clear();
+        kept.clear();
+        for (size_t j = 0; j < n; ++j)
+            if (flags[j] == 2) {
+                to_score.push_back(&fresh[j]);
+                kept.push_back((int)j);
+            }
+        t1 = now(); stats.settle_seconds += t1 - t0; t0 = t1;
+        const int score_rc = score_moves(to_score);
+        t1 = now(); stats.policy_seconds += t1 - t0; t0 = t1;
+        const int eval_rc = to_eval.empty() ? 0 : eval_lane->wait();
+        t1 = now(); stats.value_wait_seconds += t1 - t0;
+        stats.eval_wait_seconds += t1 - t0;
+        t0 = t1;
         if (eval_rc) return fail("the value network's evaluation call failed");
         if (score_rc) return score_rc;
         // update_tree_from_terminating_nodes, :422-453
         size_t e = 0;
         for (size_t j = 0; j < n; ++j) {
-            Node& c = nodes[first_child + j];
+            Node& c = fresh[j];
             if (e < to_eval.size() && to_eval[e] == (int)j) {
                 const float s = eval_scores[e++] - cfg.eval_zero_shift;
                 TTEntry& t = entry(c.b.hash);  // add_evaluated_boards_to_tt, transposition_table.py:138-148
@@ -458,6 +542,7 @@ struct bfs_search {
                 update_from_value(c.parent, -c.best_value, c.prev_move);
             }
         }
+        t1 = now(); stats.update_seconds += t1 - t0; t0 = t1;
         // parents with moves left go back to the open list, open children join it
         to_insert->clear();
         insert_scores->clear();
@@ -466,20 +551,31 @@ struct bfs_search {
                 to_insert->push_back(batch[j]);
                 insert_scores->push_back(parent_next_score[j]);
             }
-        // compact the children that stay: move them down over the discarded ones
-        size_t keep = first_child;
-        for (size_t j = 0; j < n; ++j) {
-            Node& c = nodes[first_child + j];
-            if (c.depth != 0 && !c.terminated) {
-                if (keep != first_child + j) nodes[keep] = c;
-                Node& k = nodes[keep];
-                const float s = next_best_move(k);
-                to_insert->push_back((int)keep);
-                insert_scores->push_back(s);
-                ++keep;
+        // open children (exactly the ones whose moves were scored, in that order) move to the arena and join the list
+        const size_t base = nodes.size();
+        if (base + kept.size() > max_nodes)
+            return fail("search arena would exceed its limit of %zu nodes (bfs_config.max_nodes)", max_nodes);
+        nodes.resize(base + kept.size());
+        pool->for_range(kept.size(), kGrain, [&](size_t b, size_t e) {
+            for (size_t i = b; i < e; ++i) {
+                const Node& src = fresh[kept[i]];
+                Node& dst = nodes[base + i];
+                if (i + 8 < e) {   // the end of the arena is cold memory: ask for the lines a few nodes ahead
+                    const char* p = reinterpret_cast<const char*>(&nodes[base + i + 8]);
+                    for (size_t off : {(size_t)0, (size_t)64, offsetof(Node, moves), offsetof(Node, moves) + 64,
+                                       offsetof(Node, move_scores), offsetof(Node, move_scores) + 64, offsetof(Node, move_scores) + 128})
+                        __builtin_prefetch(p + off, 1);
+                }
+                std::memcpy(static_cast<void*>(&dst), static_cast<const void*>(&src), offsetof(Node, moves));
+                std::memcpy(dst.moves, src.moves, src.n_moves * sizeof(Move));
+                std::memcpy(dst.move_scores, src.move_scores, src.n_moves * sizeof(float));
             }
+        });
+        for (size_t i = 0; i < kept.size(); ++i) {
+            to_insert->push_back((int)(base + i));
+            insert_scores->push_back(first_score[i]);
         }
-        nodes.resize(keep);
+        stats.compact_seconds += now() - t0;
         return 0;
     }
 
@@ -487,7 +583,7 @@ struct bfs_search {
     int make_root(const Board& start, int depth, float separator) {
         nodes.clear();
         clear_bins();
-        nodes.emplace_back();
+        nodes.resize(1);
         Node& r = nodes[0];
         r.b = start;
         to_whites_perspective(r.b);
@@ -516,11 +612,10 @@ struct bfs_search {
             return 0;
         }
         if (!settle(r)) return 0;
-        double wait = 0;
-        std::vector<Node*> one{&r};
-        if (int rc = score_moves(one, &wait)) return rc;
-        stats.eval_wait_seconds += wait;
-        next_best_move(r);
+        const double t0 = now();
+        to_score.assign(1, &nodes[0]);
+        if (int rc = score_moves(to_score)) return rc;
+        stats.policy_seconds += now() - t0;
         return 0;
     }
 
@@ -539,8 +634,9 @@ struct bfs_search {
                     break;
                 }
                 if (to_insert.empty() && in_bins == 0) break;
+                const double ts = now();
                 batch = insert_and_get_batch(to_insert, scores);
-                if (nodes.size() > ((size_t)1 << 24)) return fail("search arena exceeds 2^24 nodes");
+                stats.select_seconds += now() - ts;
             }
         }
         *value = nodes[0].best_value;
@@ -794,11 +890,46 @@ extern "C" int bfs_search_create(bfs_search** out, const bfs_config* cfg) {
     std::sort(s->bins_desc.begin(), s->bins_desc.end(), [](float a, float b) { return a > b; });
     s->cfg.bin_edges = nullptr;
     s->bins.resize(s->bins_desc.size() + 1);
-    s->tt.assign((size_t)1 << cfg->tt_bits, TTEntry());
+    if (cfg->threads < 0 || cfg->threads > 256) {
+        delete s;
+        return fail("bfs_search_create: threads %d out of range 0..256", cfg->threads);
+    }
+    int threads = cfg->threads;
+    if (threads == 0) threads = (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    if (cfg->max_nodes) s->max_nodes = cfg->max_nodes;
+    try {
+        s->tt.assign((size_t)1 << cfg->tt_bits, TTEntry());
+        s->pool.reset(new Pool(threads));       // runs with the workers it could start
+        s->eval_lane.reset(new Lane());
+    } catch (const std::exception& e) {
+        delete s;
+        return fail("bfs_search_create: %s", e.what());
+    }
+    if (!s->eval_lane->ok()) {
+        delete s;
+        return fail("bfs_search_create: could not start the evaluation thread");
+    }
+    s->cfg.threads = s->pool->threads();
     s->tt_mask = ((u64)1 << cfg->tt_bits) - 1;
     *out = s;
     return 0;
 }
+
+extern "C" int bfs_search_threads(const bfs_search* s) { return s ? s->pool->threads() : 0; }
+
+namespace {
+// the arena, the open list and the evaluators' buffers grow inside a search: out of memory becomes an error code
+template <class F>
+int guarded(const char* what, F&& f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        return fail("%s: out of memory", what);
+    } catch (const std::exception& e) {
+        return fail("%s: %s", what, e.what());
+    }
+}
+}  // namespace
 
 extern "C" void bfs_search_destroy(bfs_search* s) { delete s; }
 
@@ -817,7 +948,7 @@ extern "C" int bfs_zero_window(bfs_search* s, const char* fen, int depth, float 
     if (!s || !fen || !value || !board_from_fen(fen, &b)) return fail("bfs_zero_window: bad argument");
     if (depth < 0 || depth >= kMaxDepth) return fail("bfs_zero_window: depth %d out of range", depth);
     // code_testing.py:606: the separator handed to the tree is the float just below the one asked for
-    return s->zero_window(b, depth, std::nextafterf(separator, FMIN), value);
+    return guarded("bfs_zero_window", [&] { return s->zero_window(b, depth, std::nextafterf(separator, FMIN), value); });
 }
 
 extern "C" int bfs_mtd_f(bfs_search* s, const char* fen, int depth, float first_guess, float guess_increment, float* value,
@@ -826,7 +957,7 @@ extern "C" int bfs_mtd_f(bfs_search* s, const char* fen, int depth, float first_
     if (!s || !fen || !value || !move || !board_from_fen(fen, &b)) return fail("bfs_mtd_f: bad argument");
     if (depth < 1 || depth >= kMaxDepth) return fail("bfs_mtd_f: depth %d out of range", depth);
     Move m;
-    if (int rc = s->mtd_f(b, depth, first_guess, guess_increment, value, &m)) return rc;
+    if (int rc = guarded("bfs_mtd_f", [&] { return s->mtd_f(b, depth, first_guess, guess_increment, value, &m); })) return rc;
     move[0] = m.from; move[1] = m.to; move[2] = m.promo;
     return 0;
 }
@@ -841,7 +972,7 @@ extern "C" int bfs_iterative_deepening(bfs_search* s, const char* fen, const int
     Move m = kNoMove;
     for (int i = 0; i < n_depths; ++i) {
         if (depths[i] < 1 || depths[i] >= kMaxDepth) return fail("bfs_iterative_deepening: depth %d out of range", depths[i]);
-        if (int rc = s->mtd_f(b, depths[i], guess, 0.05f, &guess, &m)) return rc;
+        if (int rc = guarded("bfs_iterative_deepening", [&] { return s->mtd_f(b, depths[i], guess, 0.05f, &guess, &m); })) return rc;
     }
     *value = guess;
     move[0] = m.from; move[1] = m.to; move[2] = m.promo;

@@ -44,6 +44,9 @@ typedef struct {
     void* move_user;
     bfs_move_start_fn move_start;    // both null: moves are scored np.linspace(0, 1, total) over the
     bfs_move_finish_fn move_finish;  // batch, the reference's fake policy (code_testing.py:634-640)
+    size_t max_nodes;           // arena limit in nodes, checked before the arena grows; 0 = 2^24 (about 14 GB)
+    int threads;                // host threads for the per-node loops of a batch (the reference's prange,
+                                // numba_board.py:242-266); 0 = min(8, hardware threads); results do not depend on it
 } bfs_config;
 
 typedef struct {
@@ -55,6 +58,16 @@ typedef struct {
     uint64_t max_batch;         // largest evaluation batch
     double seconds;             // wall time inside search calls
     double eval_wait_seconds;   // of which waiting for the evaluators
+    uint64_t eval_calls;        // value-network calls (boards_evaluated / eval_calls = mean evaluation batch)
+    uint64_t policy_calls;      // move-scoring calls
+    // where the wall time of do_iteration goes (seconds; their sum + select_seconds ~ seconds):
+    double expand_seconds;      // children made, depth-0 children checked and packed into records (threads)
+    double settle_seconds;      // other children: draw / table / mate checks, move generation (threads)
+    double policy_seconds;      // move-scoring: packing (threads) + both evaluator calls
+    double value_wait_seconds;  // waiting for the value network after all of the above
+    double update_seconds;      // scores into the tree and the transposition table (one thread)
+    double compact_seconds;     // open children kept, re-insertion lists
+    double select_seconds;      // open list: insert_and_get_batch
 } bfs_stats;
 
 typedef struct bfs_search bfs_search;
@@ -85,6 +98,7 @@ int bfs_negamax(const char* fen, int depth, bfs_board_eval_fn eval, void* user, 
 
 int bfs_search_create(bfs_search** out, const bfs_config* cfg);
 void bfs_search_destroy(bfs_search* s);
+int bfs_search_threads(const bfs_search* s);   // host threads the instance runs its per-node loops on
 void bfs_search_clear_tt(bfs_search* s);
 void bfs_search_stats(const bfs_search* s, bfs_stats* out, int reset);
 // zero_window_search of code_testing.py:598-625: value of the position searched to `depth` against `separator`

@@ -1,0 +1,204 @@
+// Host threads of the search driver: a fork-join pool for the per-node work of one batch (child
+// construction, draw / table / mate checks, move generation, record packing: the loops the reference
+// runs under numba prange, numba_board.py:242-266) and a lane that runs evaluator calls beside it.
+//
+// An iteration of the search lasts tens of microseconds to a few milliseconds, so waiting threads spin
+// for a short while before they sleep: a sleeping thread costs a futex wake (20-50 us) per hand-over,
+// which is as long as a small iteration.
+#pragma once
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstddef>
+#include <cstdint>
+#include <deque>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace bfs {
+
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+}
+
+// A generation counter that waiters watch: spin for `spin_us`, then sleep on the condition variable.
+class Gate {
+public:
+    explicit Gate(int spin_us = 200) : spin_us_(spin_us) {}
+    uint64_t value() const { return gen_.load(); }
+    void bump() {
+        gen_.fetch_add(1);
+        if (sleepers_.load() > 0) {
+            std::lock_guard<std::mutex> lk(m_);
+            cv_.notify_all();
+        }
+    }
+    // returns once the counter differs from `seen`
+    void wait_change(uint64_t seen) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0;; ++i) {
+            if (gen_.load() != seen) return;
+            cpu_relax();
+            if ((i & 63) == 63 &&
+                std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us_)
+                break;
+        }
+        std::unique_lock<std::mutex> lk(m_);
+        sleepers_.fetch_add(1);
+        cv_.wait(lk, [&] { return gen_.load() != seen; });
+        sleepers_.fetch_sub(1);
+    }
+
+private:
+    std::atomic<uint64_t> gen_{0};
+    std::atomic<int> sleepers_{0};
+    std::mutex m_;
+    std::condition_variable cv_;
+    int spin_us_;
+};
+
+// Fork-join over an index range; the calling thread takes part.  One job at a time.
+class Pool {
+public:
+    // threads = total including the caller; workers that cannot be started are done without
+    explicit Pool(int threads) {
+        for (int i = 1; i < threads; ++i) {
+            try {
+                workers_.emplace_back([this] { worker(); });
+            } catch (...) {
+                break;
+            }
+        }
+    }
+    ~Pool() {
+        stop_.store(true);
+        start_.bump();
+        for (auto& t : workers_) t.join();
+    }
+    Pool(const Pool&) = delete;
+    Pool& operator=(const Pool&) = delete;
+    int threads() const { return (int)workers_.size() + 1; }
+
+    // f(begin, end) over [0, n) in pieces of `grain`; f must not throw
+    template <class F>
+    void for_range(size_t n, size_t grain, F&& f) {
+        if (workers_.empty() || n <= grain) {
+            if (n) f((size_t)0, n);
+            return;
+        }
+        struct Ctx { F* f; } ctx{&f};
+        call_ = [](void* c, size_t b, size_t e) { (*static_cast<Ctx*>(c)->f)(b, e); };
+        ctx_ = &ctx;
+        total_ = n;
+        grain_ = grain;
+        next_.store(0);
+        remaining_.store((int)workers_.size());
+        start_.bump();
+        drain();
+        while (remaining_.load() != 0) cpu_relax();
+    }
+
+private:
+    void drain() {
+        for (;;) {
+            const size_t b = next_.fetch_add(grain_);
+            if (b >= total_) return;
+            call_(ctx_, b, b + grain_ < total_ ? b + grain_ : total_);
+        }
+    }
+    void worker() {
+        uint64_t seen = 0;
+        for (;;) {
+            start_.wait_change(seen);
+            seen = start_.value();   // one job at a time: the caller waits for every worker before the next bump
+            if (stop_.load()) return;
+            drain();
+            remaining_.fetch_sub(1);
+        }
+    }
+
+    std::vector<std::thread> workers_;
+    Gate start_;
+    std::atomic<bool> stop_{false};
+    std::atomic<size_t> next_{0};
+    std::atomic<int> remaining_{0};
+    size_t total_ = 0, grain_ = 1;
+    void (*call_)(void*, size_t, size_t) = nullptr;
+    void* ctx_ = nullptr;
+};
+
+// One thread that runs the calls handed to it, in order; wait() returns when all of them are done.
+class Lane {
+public:
+    using Fn = int (*)(void* arg);
+    Lane() {
+        try {
+            thread_ = std::thread([this] { run(); });
+            ok_ = true;
+        } catch (...) {
+            ok_ = false;
+        }
+    }
+    ~Lane() {
+        if (!ok_) return;
+        stop_.store(true);
+        work_.bump();
+        thread_.join();
+    }
+    Lane(const Lane&) = delete;
+    Lane& operator=(const Lane&) = delete;
+    bool ok() const { return ok_; }
+
+    void submit(Fn fn, void* arg) {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            q_.push_back({fn, arg});
+        }
+        submitted_.fetch_add(1);
+        work_.bump();
+    }
+    // nonzero if any call since the last wait() failed
+    int wait() {
+        while (done_.load() != submitted_.load()) cpu_relax();
+        return rc_.exchange(0);
+    }
+
+private:
+    struct Job { Fn fn; void* arg; };
+    void run() {
+        uint64_t seen = 0;
+        for (;;) {
+            for (;;) {
+                Job j;
+                {
+                    std::lock_guard<std::mutex> lk(m_);
+                    if (q_.empty()) break;
+                    j = q_.front();
+                    q_.pop_front();
+                }
+                const int rc = j.fn(j.arg);
+                if (rc) rc_.store(rc);
+                done_.fetch_add(1);
+            }
+            if (stop_.load()) return;
+            work_.wait_change(seen);
+            seen = work_.value();
+        }
+    }
+
+    std::thread thread_;
+    bool ok_ = false;
+    Gate work_;
+    std::atomic<bool> stop_{false};
+    std::atomic<uint64_t> submitted_{0}, done_{0};
+    std::atomic<int> rc_{0};
+    std::mutex m_;
+    std::deque<Job> q_;
+};
+
+}  // namespace bfs

@@ -26,13 +26,17 @@ class Config(_c.Structure):
     _fields_ = [("max_batch_size", _c.c_size_t), ("tt_bits", _c.c_int), ("bin_edges", _c.POINTER(_c.c_float)),
                 ("n_bin_edges", _c.c_size_t), ("bin_zero_shift", _c.c_float), ("eval_zero_shift", _c.c_float),
                 ("eval_user", _c.c_void_p), ("board_eval", _c.c_void_p), ("move_user", _c.c_void_p),
-                ("move_start", _c.c_void_p), ("move_finish", _c.c_void_p)]
+                ("move_start", _c.c_void_p), ("move_finish", _c.c_void_p), ("max_nodes", _c.c_size_t),
+                ("threads", _c.c_int)]
 
 
 class Stats(_c.Structure):
     _fields_ = [("iterations", _c.c_uint64), ("nodes_out", _c.c_uint64), ("nodes_in", _c.c_uint64),
                 ("boards_evaluated", _c.c_uint64), ("moves_scored", _c.c_uint64), ("max_batch", _c.c_uint64),
-                ("seconds", _c.c_double), ("eval_wait_seconds", _c.c_double)]
+                ("seconds", _c.c_double), ("eval_wait_seconds", _c.c_double), ("eval_calls", _c.c_uint64),
+                ("policy_calls", _c.c_uint64), ("expand_seconds", _c.c_double), ("settle_seconds", _c.c_double),
+                ("policy_seconds", _c.c_double), ("value_wait_seconds", _c.c_double), ("update_seconds", _c.c_double),
+                ("compact_seconds", _c.c_double), ("select_seconds", _c.c_double)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -71,6 +75,8 @@ def load():
         lib.bfs_search_create.argtypes = [_c.POINTER(_c.c_void_p), _c.POINTER(Config)]
         lib.bfs_search_destroy.argtypes = [_c.c_void_p]
         lib.bfs_search_destroy.restype = None
+        lib.bfs_search_threads.argtypes = [_c.c_void_p]
+        lib.bfs_search_threads.restype = _c.c_int
         lib.bfs_search_clear_tt.argtypes = [_c.c_void_p]
         lib.bfs_search_clear_tt.restype = None
         lib.bfs_search_stats.argtypes = [_c.c_void_p, _c.POINTER(Stats), _c.c_int]
@@ -171,7 +177,11 @@ class Search:
     """One search instance: transposition table, open-node bins, evaluator hooks."""
 
     def __init__(self, board_eval=None, eval_user=None, move_start=None, move_finish=None, move_user=None,
-                 max_batch_size=5000, tt_bits=22, bin_edges=None, bin_zero_shift=0.0, eval_zero_shift=0.0):
+                 max_batch_size=5000, tt_bits=22, bin_edges=None, bin_zero_shift=0.0, eval_zero_shift=0.0,
+                 max_nodes=0, threads=0):
+        """max_nodes: limit of the node arena (0 = 2^24 nodes, about 14 GB); a search that would pass it fails
+        with an error instead of growing.  threads: host threads for the per-node loops of a batch (0 = up to 8);
+        results do not depend on it."""
         self._lib = load()
         if bin_edges is None:
             bin_edges = np.linspace(-4000, 4000, 1000)   # code_testing.py:602
@@ -190,7 +200,7 @@ class Search:
         cfg = Config(int(max_batch_size), int(tt_bits), self._bins.ctypes.data_as(_c.POINTER(_c.c_float)), self._bins.size,
                      float(bin_zero_shift), float(eval_zero_shift), eval_user,
                      ptr(board_eval, BOARD_EVAL_FN) or material_eval_pointer(), move_user,
-                     ptr(move_start, MOVE_START_FN), ptr(move_finish, MOVE_FINISH_FN))
+                     ptr(move_start, MOVE_START_FN), ptr(move_finish, MOVE_FINISH_FN), int(max_nodes), int(threads))
         self._s = _c.c_void_p()
         _check(self._lib.bfs_search_create(_c.byref(self._s), _c.byref(cfg)))
 
@@ -237,6 +247,10 @@ class Search:
         st = Stats()
         self._lib.bfs_search_stats(self._s, _c.byref(st), 1 if reset else 0)
         return st.as_dict()
+
+    @property
+    def threads(self):
+        return self._lib.bfs_search_threads(self._s)
 
     def clear_tt(self):
         self._lib.bfs_search_clear_tt(self._s)

@@ -233,3 +233,46 @@ def test_push_record_matches_push_on_fens():
             assert np.array_equal(child[:82], S.record_from_fen(S.push(fen, mv))[:82])
     with pytest.raises(RuntimeError):
         S.push_record(S.record_from_fen(FENS[0]), [12, 36, 0])
+
+
+def test_search_does_the_same_thing_on_any_number_of_host_threads():
+    """The per-node loops of a batch run on a thread pool (the reference's prange, numba_board.py:242-266);
+    everything that orders nodes stays on one thread, so value, move and every counter are the same."""
+    runs = []
+    for threads in (1, 2, 5):
+        s = S.Search(max_batch_size=64, tt_bits=16, threads=threads)   # small batches: many pool hand-overs
+        assert s.threads == threads
+        out = []
+        for fen in FENS[:4]:
+            value, move = s.iterative_deepening(fen, [1, 2, 3, 4])
+            out.append((value, tuple(int(x) for x in move)))
+        st = s.stats()
+        s.close()
+        runs.append((out, {k: st[k] for k in ("iterations", "nodes_out", "nodes_in", "boards_evaluated", "moves_scored",
+                                              "max_batch", "eval_calls", "policy_calls")}))
+    assert runs[0] == runs[1] == runs[2]
+    assert runs[0][1]["eval_calls"] > 0 and runs[0][1]["boards_evaluated"] >= runs[0][1]["eval_calls"]
+
+
+def test_stage_times_add_up_to_the_search_time():
+    s = S.Search(max_batch_size=512, tt_bits=16, threads=2)
+    s.iterative_deepening(FENS[1], [1, 2, 3, 4])
+    st = s.stats()
+    s.close()
+    stages = sum(st[k] for k in ("expand_seconds", "settle_seconds", "policy_seconds", "value_wait_seconds",
+                                 "update_seconds", "compact_seconds", "select_seconds"))
+    assert 0 < stages <= st["seconds"] * 1.001
+    assert stages >= 0.8 * st["seconds"]
+
+
+def test_arena_limit_is_an_error_not_a_crash():
+    """bfs_config.max_nodes is checked before the arena grows."""
+    s = S.Search(max_batch_size=512, tt_bits=16, max_nodes=2000)
+    with pytest.raises(RuntimeError, match="arena would exceed its limit of 2000 nodes"):
+        s.iterative_deepening(FENS[1], [1, 2, 3, 4, 5])
+    # the instance stays usable
+    value, move = s.iterative_deepening(FENS[2], [1, 2])
+    assert S.is_legal(FENS[2], [move])[0][0]
+    s.close()
+    with pytest.raises(RuntimeError, match="threads"):
+        S.Search(threads=1000)

@@ -22,23 +22,30 @@ def main():
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--no-policy", action="store_true")
     ap.add_argument("--cpu-material", action="store_true", help="no GPU: the reference's material-count fake (host-side ceiling)")
+    ap.add_argument("--threads", type=int, default=0, help="host threads of the search (0 = up to 8)")
+    ap.add_argument("--fens", type=int, default=7, help="use the first N of the 7 test positions")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     from batch_first_amd import search as S, weights as W
     from tests_fens import FENS
 
     if args.cpu_material:
-        make = lambda: S.Search(max_batch_size=args.batch, tt_bits=22)
+        make = lambda: S.Search(max_batch_size=args.batch, tt_bits=22, threads=args.threads)
         closer = lambda: None
     else:
         from batch_first_amd import chestimator
         bp, _, closer = chestimator.get_inference_functions(W.make_weights(seed=1234, bn="perturbed"), dtype=args.dtype,
                                                             policy_weights=W.make_policy_weights(seed=4321))
-        make = lambda: S.Search.on_gpu(bp, use_policy=not args.no_policy, max_batch_size=args.batch, tt_bits=22)
+        make = lambda: S.Search.on_gpu(bp, use_policy=not args.no_policy, max_batch_size=args.batch, tt_bits=22, threads=args.threads)
     rows = []
-    total = {"nodes_out": 0, "boards_evaluated": 0, "moves_scored": 0, "seconds": 0.0, "eval_wait_seconds": 0.0, "iterations": 0}
-    for fen in FENS:
+    stages = ["expand_seconds", "settle_seconds", "policy_seconds", "value_wait_seconds", "update_seconds",
+              "compact_seconds", "select_seconds"]
+    total = {"nodes_out": 0, "boards_evaluated": 0, "moves_scored": 0, "seconds": 0.0, "eval_wait_seconds": 0.0, "iterations": 0,
+             "eval_calls": 0, "policy_calls": 0, **{k: 0.0 for k in stages}}
+    threads = 0
+    for fen in FENS[:args.fens]:
         s = make()
+        threads = s.threads
         t0 = time.perf_counter()
         value, move = s.iterative_deepening(fen, list(range(1, args.depth + 1)))
         wall = time.perf_counter() - t0
@@ -56,7 +63,13 @@ def main():
                                           "material-count fake on the host" if args.cpu_material else
                                           "value network %s on the GPU%s" % (args.dtype, "" if args.no_policy else " + move-scoring network")),
            "nodes_per_s": total["nodes_out"] / total["seconds"], "evals_per_s": total["boards_evaluated"] / total["seconds"],
-           "eval_wait_fraction": total["eval_wait_seconds"] / total["seconds"], **total, "positions": rows}
+           "eval_wait_fraction": total["eval_wait_seconds"] / total["seconds"],
+           "mean_eval_batch": total["boards_evaluated"] / max(total["eval_calls"], 1),
+           "max_eval_batch": max(r["max_batch"] for r in rows),
+           "mean_nodes_per_iteration": total["nodes_out"] / max(total["iterations"], 1),
+           "host_threads": threads,
+           "stage_share": {k[:-8]: total[k] / total["seconds"] for k in stages},
+           **total, "positions": rows}
     print(json.dumps({k: v for k, v in out.items() if k != "positions"}))
     if args.out:
         os.makedirs(os.path.dirname(os.path.join(ROOT, args.out)), exist_ok=True)
