@@ -63,12 +63,20 @@ constexpr int THREADS = 64 * WAVES;
 constexpr int CHUNK = kStreamChunk;    // groups per lockstep chunk
 constexpr int SHARE = CHUNK / WAVES;   // groups each wave fetches per chunk
 constexpr int SLOTS = 3;
+#ifndef BF_F32_LA
+#define BF_F32_LA 3
+#endif
+// Groups held in registers ahead of the MFMAs.  One is enough where a group feeds four 64-cycle MFMAs; in
+// stage 1 a group feeds ONE 32-cycle MFMA, and with a single group in flight every one of its 240 steps sat
+// out an LDS read (stamps, one wave per SIMD: 23.8 k cycles for 7.7 k cycles of MFMA work).
+constexpr int LA = BF_F32_LA;
+static_assert(LA >= 1 && LA <= 3 && CHUNK % (LA + 1) == 0, "the look-ahead ring must keep its phase over a chunk");
 constexpr int C2_UNROLL = 4;           // hidden tiles per loop body: 4 * 46 groups = 23 chunks
 static_assert(CHUNK % WAVES == 0, "every wave fetches whole groups");
 static_assert(kInputGroups % CHUNK == 0, "the tile loop must start on a chunk boundary");
 static_assert((kPerC2Groups * C2_UNROLL) % CHUNK == 0, "loop body must be whole chunks");
 static_assert(kC2Tiles % C2_UNROLL == 0, "");
-static_assert(kStreamPadGroups >= 3 * CHUNK, "prefetch overrun must stay inside the image");
+static_assert(kStreamPadGroups >= 3 * CHUNK + LA, "prefetch overrun must stay inside the image");
 
 constexpr int MB_W = 22;     // mailbox padded by 7 squares (largest dilation) on every side
 constexpr int MB_BYTES = 496;
@@ -91,24 +99,41 @@ struct Lds {
 struct WStream {
     const f32x4* src;      // this lane's element of this wave's share of the chunk to fetch next
     f32x4* ring;           // &lds.wring[0][0][lane]
-    f32x4* share;          // &lds.wring[0][wave * SHARE][0]: where this wave's share of slot 0 lands
+    unsigned lds_share;    // LDS byte address of &lds.wring[0][wave * SHARE][0]: where this wave's share of slot 0 lands
     int rd;                // float4 offset of the slot being read
-    f32x4 pre[2];          // group being consumed / group being read from LDS
+    f32x4 pre[LA + 1];     // group being consumed and the LA groups read from LDS ahead of it
 
     // LDS-DMA: this wave's SHARE groups of the next chunk go straight from L2 into ring slot
     // `slot_off` (lane-linear 1 KiB per instruction, exactly the layout the readers expect); no
-    // staging registers, no ds_write.
+    // staging registers, no ds_write.  One instruction per group: global address = this lane's pointer +
+    // immediate, LDS address = M0 + immediate + lane * 16.
+    // Inline asm on purpose, as in eval_bf16.hip: the compiler models the builtin (global_load_lds) as an
+    // access that may touch LDS, and while one is outstanding it turns every LDS wait into lgkmcnt(0): every
+    // second group of MFMAs then sat out the LDS read issued right in front of it (1302 such waits in the
+    // listing, 5 % of the 1x1 pair's time).  next_chunk() does the vmcnt bookkeeping instead; loads the
+    // compiler interleaves only make its own vmcnt waits stricter (vector-memory operations retire in order).
+    // M0 is written by nothing else in this kernel; tools/isa_hazards.py checks every build's listing.
     __device__ __forceinline__ void fetch_into(int slot_off) {
+        static_assert(SHARE <= 4, "immediate offsets of a global instruction reach 4095");
+#ifdef BF_ABL_NODMA   // timing ablation (wrong scores): nothing is fetched
+        return;
+#endif
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(lds_share + (unsigned)slot_off * 16u) : "memory", "m0");
 #pragma unroll
-        for (int i = 0; i < SHARE; ++i)
-            __builtin_amdgcn_global_load_lds(src + i * 64, share + slot_off + i * 64, 16, 0, 0);
+        for (int i = 0; i < SHARE; ++i) {
+            if (i == 0) asm volatile("global_load_lds_dwordx4 %0, off" ::"v"(src) : "memory");
+            if (i == 1) asm volatile("global_load_lds_dwordx4 %0, off offset:1024" ::"v"(src) : "memory");
+            if (i == 2) asm volatile("global_load_lds_dwordx4 %0, off offset:2048" ::"v"(src) : "memory");
+            if (i == 3) asm volatile("global_load_lds_dwordx4 %0, off offset:3072" ::"v"(src) : "memory");
+        }
 #ifndef BF_ABL_NOSTREAM
         src += CHUNK * 64;
 #endif
     }
     __device__ __forceinline__ void prime(const f32x4* stream, f32x4* ring_base, int lane, int wave) {
+        typedef __attribute__((address_space(3))) f32x4* lds_ptr;
         ring = ring_base + lane;
-        share = ring_base + wave * SHARE * 64;
+        lds_share = (unsigned)(uintptr_t)(lds_ptr)(ring_base + wave * SHARE * 64);
         src = stream + wave * SHARE * 64 + lane;
         fetch_into(0);                  // chunk 0
         fetch_into(CHUNK * 64);         // chunk 1
@@ -123,27 +148,39 @@ struct WStream {
         // keep the barrier behind the previous group's MFMAs: they cover the latency of the LDS read
         // just issued, which the barrier's lgkmcnt(0) would otherwise sit out with the pipe idle
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
+#ifdef BF_F32_FULLWAIT
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+        // Only chunk k has to have landed here: this wave's share of it was fetched two barriers ago, the share
+        // of chunk k+1 (one barrier ago, the SHARE youngest loads) may still be in flight.  __syncthreads() would
+        // wait for vmcnt(0), i.e. give the fetch one chunk (2048 cycles) to land instead of two.
+#ifdef BF_ABL_NOBAR   // timing ablation (races): waves do not wait for each other
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SHARE) : "memory");
+#else
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(SHARE) : "memory");
+#endif
+#endif
         __builtin_amdgcn_sched_barrier(0);
         fetch_into(free_slot);
     }
-    // Read group 0 once everything staged before it is visible.
+    // Read groups 0 .. LA-1 once everything staged before them is visible.
     __device__ __forceinline__ void start() {
         next_chunk();
-        pre[0] = ring[rd];
+#pragma unroll
+        for (int i = 0; i < LA; ++i) pre[i] = ring[rd + i * 64];
     }
     // g: stream group index, a compile-time constant after unrolling; groups are taken in order.
-    // Returns group g (already in registers) and starts the LDS read of group g+1, so the read's
-    // latency hides under group g's MFMAs.  When g+1 opens a chunk, the barrier happens here: this
+    // Returns group g (already in registers) and starts the LDS read of group g+LA, so the read's
+    // latency hides under the MFMAs of groups g .. g+LA-1.  When g+LA opens a chunk, the barrier happens here: this
     // wave holds all of the old chunk in registers by now.
     __device__ __forceinline__ f32x4 take(int g) {
-        const int nx = g + 1;
+        const int nx = g + LA;
         if (nx % CHUNK == 0) next_chunk();
-        pre[nx & 1] = ring[rd + (nx % CHUNK) * 64];
+        pre[nx % (LA + 1)] = ring[rd + (nx % CHUNK) * 64];
         // pin the read ahead of group g's MFMAs (the scheduler otherwise sinks it to its use and
         // the wave sits out the LDS latency with the matrix pipe idle)
         __builtin_amdgcn_sched_barrier(0);
-        return pre[g & 1];
+        return pre[g % (LA + 1)];
     }
 };
 
@@ -393,6 +430,10 @@ __global__ __launch_bounds__(THREADS, 2) void k_eval_f32(const uint8_t* __restri
     }
 
     BF_STAMP(5);
+    // The stream's prefetch runs two chunks past the last group used; the compiler does not know of the asm
+    // LDS-DMA, so nothing else waits for it: no piece may still be on its way into this workgroup's LDS when
+    // the workgroup ends and the CU hands the allocation to the next one.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (MODE == 2) {
         if (live) {
             float* out = scores + (size_t)board * 2048;
