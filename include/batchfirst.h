@@ -73,7 +73,9 @@ enum {
  *                      within 1e-4 relative of the float32 CPU evaluation of the reference's graph.
  *   BF_PRECISION_BF16  batch-norm-folded weights and every activation x1..x9 rounded to bf16
  *                      (round-to-nearest-even), float32 sums, shifts, x10 and logit
- *                      (v_mfma_f32_32x32x16_bf16).  No reference counterpart: the reference runs
+ *                      (v_mfma_f32_16x16x32_bf16; the round-1 kernel on v_mfma_f32_32x32x16_bf16, same
+ *                      arithmetic, is selected by the environment variable BF_BF16_TILES=32 when the
+ *                      context is created).  No reference counterpart: the reference runs
  *                      TensorRT/TensorFlow in FP32 only (ann_creation_helper.py:182-187). */
 enum { BF_PRECISION_F32 = 0, BF_PRECISION_BF16 = 1 };
 

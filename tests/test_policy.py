@@ -191,8 +191,9 @@ def test_policy_device_ops(pweights, pgolden, golden):
 def test_policy_bf16_precision(pweights, pgolden, golden):
     """BF16 context: the move-scoring network runs on the bf16 kernel (no reference counterpart;
     bar as for the value network's bf16 precision, tests/test_gpu_bf16.py): scores within
-    5e-2 * max(|r|, rms) of the float32 oracle, and the moves of a board keep their order wherever
-    float32 separates them by more than 4x that tolerance."""
+    4e-2 * max(|r|, rms) of the float32 oracle (measured worst 2.4e-2 on the sibling groups below, 1.6e-2 here),
+    and the moves of a board keep their order wherever float32 separates them by more than 4x that tolerance.
+    Parity unpinned: the oracle is this repository's restatement of the graph."""
     from batch_first_amd import chestimator
     bp, start, closer = chestimator.get_inference_functions(W.make_weights(seed=1234, bn="perturbed"), dtype="bf16",
                                                             policy_weights=pweights)
@@ -207,9 +208,9 @@ def test_policy_bf16_precision(pweights, pgolden, golden):
     ref = pgolden["scores_f32"]
     worst = _ok(got, ref)
     print("bf16 policy: worst error / rms-floored magnitude %.2e" % worst)
-    assert worst <= 5e-2
+    assert worst <= 4e-2
     rms = float(np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
-    gap = 4 * 5e-2 * rms
+    gap = 4 * 4e-2 * rms
     pos, checked = 0, 0
     for k in pgolden["moves_per_board"].astype(np.int64):   # int64: a uint8 running sum wraps at 256
         k = int(k)
