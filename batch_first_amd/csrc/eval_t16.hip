@@ -17,8 +17,10 @@
 // after the other (the layer's 18 fragments stay in registers after the first), and the tile a column
 // tile needs from the previous layer was finished at least two tiles earlier.
 //   stage 1  B operand of a k-step = two taps x 16 planes: lanes q = 0,1 look up tap A's shifted square,
-//            q = 2,3 tap B's (a code byte from the padded byte mailbox, then that code's one-hot row from
-//            a 16-entry table); a step whose taps all miss the board for a column tile is skipped there.
+//            q = 2,3 tap B's, with ONE ds_read_b128 at an immediate offset from a one-hot image of the board
+//            (grid[12 ranks][24 files][2 halves] of 16-byte entries, written once per board; the all-ones
+//            16th plane comes from a register); a step whose taps all miss the board for a column tile is
+//            skipped there.
 //   stage 2  per pair of 16-row hidden tiles: 16 fragments (236->512), ReLU + pack, 8 fragments (512->128),
 //            software-pipelined across pairs (stream order kPairOrder).
 //   stage 3/4  3x3 layers through zero-haloed [10x10 positions][32 channels] bf16 planes private to the
@@ -65,14 +67,23 @@ static_assert(kStreamWalkGroups % CHUNK == 0 && WALK_CHUNKS % SLOTS == 0 && kStr
               "every board starts in the same phase of the ring and of the register look-ahead");
 static_assert(SHARE >= 1 && SHARE <= 4 && CHUNK % WAVES == 0 && LA <= CHUNK, "fetch_piece: up to four pieces with immediate offsets");
 
-constexpr int MB_W = 22;                 // byte mailbox padded by 7 squares on every side
-constexpr int MB_WORDS = 124;
+// Stage 1 reads its B operands from a one-hot image of the board in LDS: grid[row][col][half] of 16-byte
+// entries (8 bf16 planes each), rows -2 .. 9 and columns -7 .. 16 around the board.  Columns: the taps reach 7
+// files sideways; 24 a row makes a rank 768 bytes = three bank windows, so the two ranks of a column tile
+// never meet in a bank.  Rows: a unit is only computed when one of its two ranks lands on the board, so the
+// other is at most one rank off it (3x3 convs), two for the never-skipped 2x2 convs; a tap that is further
+// off is pointed at ranks -2, -1 instead (all zero, as every off-board entry is).  The all-ones 16th plane is
+// OR-ed in from a register, so the image is zero wherever no piece stands and can alias the activation planes.
+constexpr int GR_ROWS = 12, GR_COLS = 24, GR_ROW0 = 2, GR_COL0 = 7;
+constexpr int GR_ENTRY = 32;             // two halves of 16 bytes
+constexpr int GR_ROW_BYTES = GR_COLS * GR_ENTRY;       // 768
+constexpr int GR_BYTES = GR_ROWS * GR_ROW_BYTES;       // 9216
 constexpr int XP_W = 10;                 // activation plane padded by 1
 constexpr int POS_BYTES = 64;            // 32 channels bf16
 constexpr int ROW_BYTES = XP_W * POS_BYTES;            // 640
 constexpr int PLANE_BYTES = XP_W * ROW_BYTES;          // 6400
 constexpr int BOARD_BYTES = 2 * PLANE_BYTES;
-static_assert(MB_WORDS * 4 <= PLANE_BYTES, "the byte mailbox aliases plane 0");
+static_assert(GR_BYTES <= BOARD_BYTES && GR_BYTES % 1024 == 0, "the one-hot image aliases the activation planes");
 
 struct Lds {
     f32x4 wring[SLOTS][CHUNK][64];                       // shared A-fragment ring, 64 KiB
@@ -227,7 +238,9 @@ constexpr int kMaxUnits = 176, kMaxJobs = 8;
 struct S1Table {
     int n;
     short conv[kMaxUnits], step[kMaxUnits], t[kMaxUnits], g0[kMaxUnits];
-    short off_a[kMaxUnits], off_b[kMaxUnits];        // byte-mailbox offsets of the two taps (tile 0's square)
+    int imm[kMaxUnits];                              // grid byte offset common to both taps of the unit (the smaller one)
+    int da[kMaxUnits], db[kMaxUnits];                // what tap A's / tap B's lanes add to it (one of them is 0)
+    bool new_base[kMaxUnits];                        // (da, db) differs from the previous unit's
     bool first_of_step[kMaxUnits], first_of_tile[kMaxUnits];
     short njobs[kMaxUnits];
     short job[kMaxUnits][kMaxJobs];                  // pack jobs run after the unit's MFMAs: t * 32 + dword
@@ -248,8 +261,19 @@ constexpr S1Table make_s1_table() {
             for (int t = 0; t < 4; ++t) {
                 if (!step_valid(i, s, t)) continue;
                 T.conv[n] = (short)i; T.step[n] = (short)s; T.t[n] = (short)t; T.g0[n] = (short)g;
-                T.off_a[n] = (short)(tap_dr(i, tp.a) * MB_W + tap_df(i, tp.a));
-                T.off_b[n] = tp.b >= 0 ? (short)(tap_dr(i, tp.b) * MB_W + tap_df(i, tp.b)) : T.off_a[n];
+                // ranks of the two taps for this column tile; a tap whose ranks leave the grid reads ranks -2, -1
+                auto grid_dr = [&](int tap) {
+                    const int dr = tap_dr(i, tap);
+                    const bool in_grid = 2 * t + dr >= -GR_ROW0 && 2 * t + 1 + dr <= GR_ROWS - GR_ROW0 - 1;
+                    return in_grid ? dr : -2 * t - 2;
+                };
+                const int tb = tp.b >= 0 ? tp.b : tp.a;
+                const int off_a = ((grid_dr(tp.a) + 2 * t + GR_ROW0) * GR_COLS + tap_df(i, tp.a) + GR_COL0) * GR_ENTRY;
+                const int off_b = ((grid_dr(tb) + 2 * t + GR_ROW0) * GR_COLS + tap_df(i, tb) + GR_COL0) * GR_ENTRY;
+                T.imm[n] = off_a < off_b ? off_a : off_b;
+                T.da[n] = off_a - T.imm[n];
+                T.db[n] = off_b - T.imm[n];
+                T.new_base[n] = n == 0 || T.da[n] != T.da[n - 1] || T.db[n] != T.db[n - 1];
                 T.first_of_step[n] = first;
                 T.first_of_tile[n] = !seen[t];
                 first = false;
@@ -330,32 +354,40 @@ __device__ __forceinline__ void s1_dump(int t, int d, unsigned p, int q, int c16
     }
 }
 
-// mb: this lane's square of column tile 0 in the byte mailbox; tbl: the one-hot table at this lane's plane
-// half; q2: lane quarter >= 2 (looks up the step's second tap).
+// grid0: this lane's entry of column tile 0's square at tap offset (0, 0), rank -GR_ROW0, file -GR_COL0 (so that
+// every unit's offset is a non-negative immediate), at this lane's plane half; q2: lane quarter >= 2 (looks up
+// the step's second tap); ones: the all-ones 16th plane of this lane's half (bf16 1.0 in element 7 of half 1).
 template <bool DBG>
-__device__ __forceinline__ void stage1(WStream& ws, const unsigned char* mb, const u32x4* tbl, bool q2, unsigned (&X)[4][kX1Dwords],
-                                       int q, int c16, float* dbg_board) {
+__device__ __forceinline__ void stage1(WStream& ws, unsigned grid0, bool q2, unsigned ones, unsigned (&X)[4][kX1Dwords],
+                                       int q, int c16, float* dbg_board, unsigned* stamps) {
+    typedef const __attribute__((address_space(3))) u32x4* lds_entry;
 #ifndef T16_S1_Q
 #define T16_S1_Q 4
 #endif
-    constexpr int CQ = T16_S1_Q, BQ = T16_S1_Q, NC = CQ + BQ;   // codes run CQ + BQ units ahead, rows BQ units
+    constexpr int BQ = T16_S1_Q;   // B operands are read BQ units ahead of their MFMAs
     constexpr int N = kS1.n;
-    int code[NC];
     u32x4 b[BQ];
     f32x4 acc[2][4][4];   // [conv parity][row tile][column tile]
     bf16x8 fr[4];
-    auto read_code = [&](int u) -> int {
+    unsigned base = grid0;   // LDS byte address: grid0 + what this lane's tap adds for the units being read
+    auto read_b = [&](int u) -> u32x4 {
         const int uu = u < N ? u : N - 1;   // look-ahead past the end re-reads the last unit (harmless)
-        const int off = q2 ? kS1.off_b[uu] : kS1.off_a[uu];
-        return mb[off + 2 * kS1.t[uu] * MB_W];
+        if (u < N && kS1.new_base[uu]) {
+            base = grid0 + (unsigned)(q2 ? kS1.db[uu] : kS1.da[uu]);
+            asm volatile("" : "+v"(base));   // computed here, once per change, not hoisted for all units
+        }
+        return *(lds_entry)(uintptr_t)(base + (unsigned)kS1.imm[uu]);
     };
 #pragma unroll
-    for (int u = 0; u < NC; ++u) code[u] = read_code(u);
-#pragma unroll
-    for (int u = 0; u < BQ; ++u) b[u] = tbl[code[u] * 2];
+    for (int u = 0; u < BQ; ++u) b[u] = read_b(u);
+    b[0].w |= ones;
 #pragma unroll
     for (int u = 0; u < N; ++u) {
         const int I = kS1.conv[u], t = kS1.t[u], par = I & 1;
+#ifdef BF_STAMPS   // first unit of convs 1, 2, 4, 6, 7: slots 8..12; the tail packs: slot 13
+        if (u > 0 && kS1.conv[u - 1] != I && (I == 1 || I == 2 || I == 4 || I == 6 || I == 7))
+            stamps[I == 1 ? 8 : I == 2 ? 9 : I == 4 ? 10 : I == 6 ? 11 : 12] = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
         if (kS1.first_of_step[u]) {
 #pragma unroll
             for (int tile = 0; tile < 4; ++tile)
@@ -366,8 +398,11 @@ __device__ __forceinline__ void stage1(WStream& ws, const unsigned char* mb, con
         for (int tile = 0; tile < 4; ++tile)
             if (tile < kRowTiles[I])
                 acc[par][tile][t] = MFMA16(fr[tile], bu, kS1.first_of_tile[u] ? zero4() : acc[par][tile][t]);
-        b[u % BQ] = tbl[code[(u + BQ) % NC] * 2];
-        code[u % NC] = read_code(u + NC);
+        b[u % BQ] = read_b(u + BQ);
+        // the all-ones plane (1.0 on every square, padding included) of the NEXT unit's operand, which was read
+        // three units ago: here the OR issues under this unit's MFMAs, in front of its own MFMA it costs the
+        // wait states of a VALU result read by an MFMA
+        if (u + 1 < N) b[(u + 1) % BQ].w |= ones;
 #pragma unroll
         for (int k = 0; k < kMaxJobs; ++k)
             if (k < kS1.njobs[u]) {
@@ -377,6 +412,9 @@ __device__ __forceinline__ void stage1(WStream& ws, const unsigned char* mb, con
             }
         __builtin_amdgcn_sched_barrier(0);
     }
+#ifdef BF_STAMPS
+    stamps[13] = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
     for (int k = 0; k < 64; ++k)
         if (k < kS1.ntail) {
@@ -424,7 +462,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_t16(const uint8_t* __restri
     if (tid < 32) {
         const unsigned c = tid >> 1, hh = tid & 1, j = c & 7u;
         const unsigned one = (c != 15u && (c >> 3) == hh) ? (0x3F80u << ((j & 1u) * 16u)) : 0u;
-        u32x4 e = u32x4{0u, 0u, 0u, hh ? 0x3F800000u : 0u};  // plane 15 = 1.0 in every entry
+        u32x4 e = u32x4{0u, 0u, 0u, 0u};   // (plane 15, the all-ones plane, is OR-ed in from a register: stage1)
         e.x |= ((j >> 1) == 0u) ? one : 0u;
         e.y |= ((j >> 1) == 1u) ? one : 0u;
         e.z |= ((j >> 1) == 2u) ? one : 0u;
@@ -475,15 +513,17 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_t16(const uint8_t* __restri
     stamps[7] = (unsigned)__builtin_amdgcn_s_memrealtime();
 #endif
 
-    // ---- byte mailbox: 15 everywhere, then the board's codes -------------------------------------
-    static_assert(MB_WORDS <= 128, "");
-    reinterpret_cast<unsigned*>(region)[lane] = 0x0F0F0F0Fu;
-    reinterpret_cast<unsigned*>(region)[lane + 64] = 0x0F0F0F0Fu;
+    // ---- one-hot image of the board: zero (the planes hold the previous board's activations), then every
+    // square's two entries; a wave's LDS operations are carried out in the order it issues them
+#pragma unroll
+    for (int i = 0; i < GR_BYTES / 1024; ++i) reinterpret_cast<u32x4*>(region)[lane + 64 * i] = u32x4{0u, 0u, 0u, 0u};
     lds_order();
+    unsigned char* my_entry = region + (((lane >> 3) + GR_ROW0) * GR_COLS + (lane & 7) + GR_COL0) * GR_ENTRY;
     {
         const unsigned v = lds.next_mailbox[wave][lane >> 1];
         const unsigned c = (lane & 1) ? (v >> 4) : (v & 15u);
-        region[((lane >> 3) + 7) * MB_W + (lane & 7) + 7] = (unsigned char)c;
+        reinterpret_cast<u32x4*>(my_entry)[0] = lds.onehot[c][0];
+        reinterpret_cast<u32x4*>(my_entry)[1] = lds.onehot[c][1];
     }
     lds_order();
 
@@ -493,14 +533,18 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_t16(const uint8_t* __restri
     // ---- stage 1: input convs -> x1 as 32 packed dwords per column tile ---------------------------
     unsigned X[4][kX1Dwords];
     {
-        const unsigned char* mb = region + (rk + 7) * MB_W + file + 7;
-        const u32x4* tbl = &lds.onehot[0][q & 1];
-        stage1<DBG>(ws, mb, tbl, q >= 2, X, q, c16, dbg_board);
+        const unsigned grid0 = (unsigned)(uintptr_t)(lds_bytes)region + (rk * GR_COLS + file) * GR_ENTRY + (q & 1) * 16;
+#ifdef BF_STAMPS
+        unsigned* sp = stamps;
+#else
+        unsigned* sp = nullptr;
+#endif
+        stage1<DBG>(ws, grid0, q >= 2, (q & 1) ? 0x3F800000u : 0u, X, q, c16, dbg_board, sp);
     }
-    // the byte mailbox is dead: its bytes are halo squares of plane 0 again (one unconditional 1-KiB store)
+    // the image is dead: with this lane's square cleared the planes' halo is all zero again
     lds_order();
-    static_assert(MB_WORDS * 4 <= 1024 && 1024 <= PLANE_BYTES, "");
-    reinterpret_cast<u32x4*>(region)[lane] = u32x4{0u, 0u, 0u, 0u};
+    reinterpret_cast<u32x4*>(my_entry)[0] = u32x4{0u, 0u, 0u, 0u};
+    reinterpret_cast<u32x4*>(my_entry)[1] = u32x4{0u, 0u, 0u, 0u};
 
     BF_STAMP(2);
     // ---- stage 2: 1x1 236->512 (+ReLU) chained into 1x1 512->128 -----------------------------------

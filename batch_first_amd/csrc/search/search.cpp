@@ -139,7 +139,7 @@ struct bfs_search {
     size_t in_bins = 0;
     bfs_stats stats{};
     std::string error;
-    size_t max_nodes = (size_t)1 << 24;
+    size_t max_nodes = (size_t)1 << 22;
     std::unique_ptr<Pool> pool;      // per-node loops of a batch
     std::unique_ptr<Lane> eval_lane; // value-network calls, beside the host work on the other children
     // buffers of iterate(), kept between calls
@@ -556,6 +556,7 @@ struct bfs_search {
         if (base + kept.size() > max_nodes)
             return fail("search arena would exceed its limit of %zu nodes (bfs_config.max_nodes)", max_nodes);
         nodes.resize(base + kept.size());
+        stats.arena_peak = std::max<uint64_t>(stats.arena_peak, nodes.size());
         pool->for_range(kept.size(), kGrain, [&](size_t b, size_t e) {
             for (size_t i = b; i < e; ++i) {
                 const Node& src = fresh[kept[i]];

@@ -44,7 +44,7 @@ typedef struct {
     void* move_user;
     bfs_move_start_fn move_start;    // both null: moves are scored np.linspace(0, 1, total) over the
     bfs_move_finish_fn move_finish;  // batch, the reference's fake policy (code_testing.py:634-640)
-    size_t max_nodes;           // arena limit in nodes, checked before the arena grows; 0 = 2^24 (about 14 GB)
+    size_t max_nodes;           // arena limit in nodes (0.8 KB each), checked before the arena grows; 0 = 2^22 (3.5 GB)
     int threads;                // host threads for the per-node loops of a batch (the reference's prange,
                                 // numba_board.py:242-266); 0 = min(8, hardware threads); results do not depend on it
 } bfs_config;
@@ -68,6 +68,7 @@ typedef struct {
     double update_seconds;      // scores into the tree and the transposition table (one thread)
     double compact_seconds;     // open children kept, re-insertion lists
     double select_seconds;      // open list: insert_and_get_batch
+    uint64_t arena_peak;        // most nodes the arena held at once
 } bfs_stats;
 
 typedef struct bfs_search bfs_search;

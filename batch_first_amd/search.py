@@ -36,7 +36,7 @@ class Stats(_c.Structure):
                 ("seconds", _c.c_double), ("eval_wait_seconds", _c.c_double), ("eval_calls", _c.c_uint64),
                 ("policy_calls", _c.c_uint64), ("expand_seconds", _c.c_double), ("settle_seconds", _c.c_double),
                 ("policy_seconds", _c.c_double), ("value_wait_seconds", _c.c_double), ("update_seconds", _c.c_double),
-                ("compact_seconds", _c.c_double), ("select_seconds", _c.c_double)]
+                ("compact_seconds", _c.c_double), ("select_seconds", _c.c_double), ("arena_peak", _c.c_uint64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -179,7 +179,7 @@ class Search:
     def __init__(self, board_eval=None, eval_user=None, move_start=None, move_finish=None, move_user=None,
                  max_batch_size=5000, tt_bits=22, bin_edges=None, bin_zero_shift=0.0, eval_zero_shift=0.0,
                  max_nodes=0, threads=0):
-        """max_nodes: limit of the node arena (0 = 2^24 nodes, about 14 GB); a search that would pass it fails
+        """max_nodes: limit of the node arena (0 = 2^22 nodes, 3.5 GB); a search that would pass it fails
         with an error instead of growing.  threads: host threads for the per-node loops of a batch (0 = up to 8);
         results do not depend on it."""
         self._lib = load()

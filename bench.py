@@ -109,10 +109,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # BF_BENCH_BACKEND=gloo is a rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share
+    # devices, the score gather goes through host memory); the driver's runs use nccl (= RCCL), one GPU a rank
+    backend = os.environ.get("BF_BENCH_BACKEND", "nccl")
+    rehearsal = backend != "nccl"
+    dev_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group(backend)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    coll_dev = torch.device("cpu") if rehearsal else dev
 
     shard = args.workload == "shard2p24"
     if shard:
@@ -128,7 +137,7 @@ def main():
         recs = block.repeat((n + 65535) // 65536, 1)[:n].contiguous()
     else:
         recs = ops.records_to_tensor(positions.to_compact(positions.random_structs(n, seed=1000 + rank)), dev)
-    gathered = [torch.empty(n, dtype=torch.float32, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gathered = [torch.empty(n, dtype=torch.float32, device=coll_dev) for _ in range(world)] if (world > 1 and rank == 0) else None
 
     def fence():
         if world > 1:
@@ -139,12 +148,12 @@ def main():
         """The timed region of the contract (W warm-up steps, exactly K steps between fences, MAX over
         ranks) and then the dominant kernel alone, for one precision.  Returns (elapsed seconds of the K
         steps, kernel ms per 65 536-board launch, the context)."""
-        ctx = ops.DeviceContext(w, device=local_rank, dtype=dtype)
+        ctx = ops.DeviceContext(w, device=dev_index, dtype=dtype)
 
         def step():
             scores = torch.ops.batchfirst.eval_structs(ctx.handle, recs)
             if world > 1:
-                dist.gather(scores, gathered, dst=0)  # RCCL: scores back to the search host's rank
+                dist.gather(scores.cpu() if rehearsal else scores, gathered, dst=0)  # RCCL: scores back to the search host's rank
             return scores
 
         for _ in range(args.warmup):
@@ -156,7 +165,7 @@ def main():
         fence()
         elapsed = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         assert bool(torch.isfinite(scores).all())

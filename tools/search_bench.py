@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--no-policy", action="store_true")
     ap.add_argument("--cpu-material", action="store_true", help="no GPU: the reference's material-count fake (host-side ceiling)")
     ap.add_argument("--threads", type=int, default=0, help="host threads of the search (0 = up to 8)")
+    ap.add_argument("--max-nodes", type=int, default=1 << 24, help="arena limit in nodes (0.8 KB each)")
     ap.add_argument("--fens", type=int, default=7, help="use the first N of the 7 test positions")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
@@ -30,13 +31,13 @@ def main():
     from tests_fens import FENS
 
     if args.cpu_material:
-        make = lambda: S.Search(max_batch_size=args.batch, tt_bits=22, threads=args.threads)
+        make = lambda: S.Search(max_batch_size=args.batch, tt_bits=22, threads=args.threads, max_nodes=args.max_nodes)
         closer = lambda: None
     else:
         from batch_first_amd import chestimator
         bp, _, closer = chestimator.get_inference_functions(W.make_weights(seed=1234, bn="perturbed"), dtype=args.dtype,
                                                             policy_weights=W.make_policy_weights(seed=4321))
-        make = lambda: S.Search.on_gpu(bp, use_policy=not args.no_policy, max_batch_size=args.batch, tt_bits=22, threads=args.threads)
+        make = lambda: S.Search.on_gpu(bp, use_policy=not args.no_policy, max_batch_size=args.batch, tt_bits=22, threads=args.threads, max_nodes=args.max_nodes)
     rows = []
     stages = ["expand_seconds", "settle_seconds", "policy_seconds", "value_wait_seconds", "update_seconds",
               "compact_seconds", "select_seconds"]
@@ -68,6 +69,7 @@ def main():
            "max_eval_batch": max(r["max_batch"] for r in rows),
            "mean_nodes_per_iteration": total["nodes_out"] / max(total["iterations"], 1),
            "host_threads": threads,
+           "arena_peak_nodes": max(r["arena_peak"] for r in rows),
            "stage_share": {k[:-8]: total[k] / total["seconds"] for k in stages},
            **total, "positions": rows}
     print(json.dumps({k: v for k, v in out.items() if k != "positions"}))

@@ -44,3 +44,10 @@ rt0, rt1 = raw[:, :, 7], raw[:, :, 14]
 rt_life = ((rt1 - rt0) & M).astype(np.float64)
 ok = rt_life > 0
 print("stamp ticks per 100 MHz tick: median %.2f  => stamp clock %.3f GHz" % (np.median(life[ok] / rt_life[ok]), np.median(life[ok] / rt_life[ok]) * 0.1))
+
+# finer stamps inside stage 1 (slots 8..13): start of convs 1, 2, 4, 6, 7 and of the tail packs
+fine = np.concatenate([raw[:, :, 1:2], raw[:, :, 8:14], raw[:, :, 2:3]], axis=2)
+fd = np.diff(fine, axis=2) & M
+labels = ["conv0 (80 MFMA)", "conv1", "conv2+3", "conv4+5", "conv6", "conv7+8", "tail packs"]
+if np.any(raw[:, :, 8] != 0):
+    print("stage 1 in pieces (cycles, median):", ", ".join("%s %.0f" % (l, np.median(fd[:, :, i])) for i, l in enumerate(labels)))
