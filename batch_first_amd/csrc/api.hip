@@ -60,6 +60,9 @@ struct bf_ctx : Lane {               // the base is the value network's lane
     // which bf16 kernel a BF16 context runs: the 16x16x32 one (eval_t16.hip) unless the environment variable
     // BF_BF16_TILES=32 asked for its 32x32x16 predecessor when the context was created (A/B timing)
     bool tiles32 = false;
+    // BF_T16_TWO_KERNELS=1 at creation: records always go through k_to_mailbox first (A/B and the equality test);
+    // otherwise the 16x16x32 kernel decodes 4-byte-aligned records itself (one launch a call)
+    bool two_kernels = false;
     float* d_packed = nullptr;            // fp32 image (bf_layout.h) when precision == BF_PRECISION_F32
     unsigned char* d_image16 = nullptr;   // bf16 image (bf_layout_bf16.h) when precision == BF_PRECISION_BF16
     // move-scoring network (bf_ctx_set_policy)
@@ -157,6 +160,19 @@ int scratch_release(Lane* c, hipStream_t s) {
     BF_HIP(hipEventRecord(c->scratch_done, s));
     c->scratch_used = true;
     return BF_OK;
+}
+
+// Records -> scores (value network) on stream `s`.  `L` = the lane whose mailbox scratch the two-kernel form uses.
+int eval_from_structs(bf_ctx* c, const void* d_structs, size_t stride, size_t n, float* d_scores, hipStream_t s) {
+    if (c->precision == BF_PRECISION_BF16 && !c->tiles32 && !c->two_kernels && bf::t16_takes_records(d_structs, stride)) {
+        BF_HIP(bf::launch_eval_t16_structs(d_structs, stride, n, c->d_image16, d_scores, s));
+        return BF_OK;   // no scratch involved
+    }
+    if (int r = ensure_boards(c, n)) return r;
+    if (int r = scratch_acquire(c, s)) return r;
+    BF_HIP(bf::launch_mailbox_from_structs(d_structs, stride, n, c->d_mailbox, s));
+    BF_HIP(launch_eval(c, c->d_mailbox, n, d_scores, nullptr, s));
+    return scratch_release(c, s);
 }
 
 int read_err_flag(Lane* c, hipStream_t s) {
@@ -258,6 +274,8 @@ extern "C" int bf_ctx_create_ex(bf_ctx** out, int device, const float* h_weights
         static_assert(bf::b16::kImageBytes == bf::t16::kImageBytes && bf::b16::kOffHead == bf::t16::kOffHead, "one allocation size, one logit offset");
         const char* env = std::getenv("BF_BF16_TILES");
         c->tiles32 = env && std::strcmp(env, "32") == 0;
+        const char* two = std::getenv("BF_T16_TWO_KERNELS");
+        c->two_kernels = two && std::strcmp(two, "1") == 0;
         std::vector<unsigned char> image(bf::b16::kImageBytes);
         if (c->tiles32) bf::pack_weights_bf16(h_weights, image.data());
         else bf::pack_weights_t16(h_weights, image.data());
@@ -394,11 +412,7 @@ extern "C" int bf_eval_structs(bf_ctx* c, const void* d_structs, size_t stride, 
     if (stride < BF_NODE_EVAL_BYTES) return bf::fail(BF_E_ARG, "bf_eval_structs: stride %zu < 82", stride);
     DeviceGuard guard(c->device);
     std::lock_guard<std::mutex> lock(c->mu);
-    if (int r = ensure_boards(c, n)) return r;
-    if (int r = scratch_acquire(c, (hipStream_t)stream)) return r;
-    BF_HIP(bf::launch_mailbox_from_structs(d_structs, stride, n, c->d_mailbox, (hipStream_t)stream));
-    BF_HIP(launch_eval(c, c->d_mailbox, n, d_scores, nullptr, (hipStream_t)stream));
-    return scratch_release(c, (hipStream_t)stream);
+    return eval_from_structs(c, d_structs, stride, n, d_scores, (hipStream_t)stream);
 }
 
 // Variant of bf_eval_structs for callers that cannot allocate: the mailboxes between the two kernels
@@ -491,7 +505,6 @@ extern "C" int bf_eval_structs_host(bf_ctx* c, const void* h_structs, size_t str
         m = n;
     }
     if (m == 0) return BF_OK;
-    if (int r = ensure_boards(c, m)) return r;
     if (int r = ensure_staging(c, m * kCompact, m)) return r;
     const unsigned char* recs = static_cast<const unsigned char*>(h_structs);
     size_t k = 0;
@@ -501,11 +514,9 @@ extern "C" int bf_eval_structs_host(bf_ctx* c, const void* h_structs, size_t str
         ++k;
     }
     const bool direct = m <= direct_boards() && c->h_in_dev && c->h_scores_dev;
-    if (int r = scratch_acquire(c, c->stream)) return r;
     if (!direct) BF_HIP(hipMemcpyAsync(c->d_in, c->h_in, m * kCompact, hipMemcpyHostToDevice, c->stream));
-    BF_HIP(bf::launch_mailbox_from_structs(direct ? c->h_in_dev : c->d_in, kCompact, m, c->d_mailbox, c->stream));
-    BF_HIP(launch_eval(c, c->d_mailbox, m, direct ? c->h_scores_dev : c->d_scores, nullptr, c->stream));
-    if (int r = scratch_release(c, c->stream)) return r;
+    if (int r = eval_from_structs(c, direct ? c->h_in_dev : c->d_in, kCompact, m, direct ? c->h_scores_dev : c->d_scores, c->stream))
+        return r;
     if (!direct) BF_HIP(hipMemcpyAsync(c->h_scores, c->d_scores, m * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     BF_HIP(hipStreamSynchronize(c->stream));
     std::memcpy(h_scores, c->h_scores, m * sizeof(float));
@@ -579,14 +590,10 @@ int start_struct_shard(bf_ctx* c, const unsigned char* compact, size_t m) {
     constexpr size_t kCompact = 88;
     DeviceGuard guard(c->device);
     if (!guard.ok) return bf::fail(BF_E_HIP, "hipSetDevice(%d) failed", c->device);
-    if (int r = ensure_boards(c, m)) return r;
     if (int r = ensure_staging(c, m * kCompact, m)) return r;
     std::memcpy(c->h_in, compact, m * kCompact);
-    if (int r = scratch_acquire(c, c->stream)) return r;
     BF_HIP(hipMemcpyAsync(c->d_in, c->h_in, m * kCompact, hipMemcpyHostToDevice, c->stream));
-    BF_HIP(bf::launch_mailbox_from_structs(c->d_in, kCompact, m, c->d_mailbox, c->stream));
-    BF_HIP(launch_eval(c, c->d_mailbox, m, c->d_scores, nullptr, c->stream));
-    if (int r = scratch_release(c, c->stream)) return r;
+    if (int r = eval_from_structs(c, c->d_in, kCompact, m, c->d_scores, c->stream)) return r;
     BF_HIP(hipMemcpyAsync(c->h_scores, c->d_scores, m * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     return BF_OK;
 }
@@ -703,6 +710,20 @@ hipError_t launch_policy_features(bf_ctx* c, const uint8_t* d_mailbox, size_t n,
     return bf::launch_policy_features_f32(d_mailbox, n, c->d_policy_packed, d_x9, s);
 }
 
+// Records -> x9 (move-scoring network's tower) on stream `s`, as eval_from_structs.
+int features_from_structs(bf_ctx* c, const void* d_structs, size_t stride, size_t n, float* d_x9, hipStream_t s) {
+    Lane* L = &c->policy;
+    if (c->precision == BF_PRECISION_BF16 && !c->tiles32 && !c->two_kernels && bf::t16_takes_records(d_structs, stride)) {
+        BF_HIP(bf::launch_policy_features_t16_structs(d_structs, stride, n, c->d_policy_image16, d_x9, s));
+        return BF_OK;
+    }
+    if (int r = ensure_boards(L, n)) return r;
+    if (int r = scratch_acquire(L, s)) return r;
+    BF_HIP(bf::launch_mailbox_from_structs(d_structs, stride, n, L->d_mailbox, s));
+    BF_HIP(launch_policy_features(c, L->d_mailbox, n, d_x9, s));
+    return scratch_release(L, s);
+}
+
 const float* policy_logit_w(const bf_ctx* c) {
     if (c->precision == BF_PRECISION_BF16) return reinterpret_cast<const float*>(c->d_policy_image16 + bf::b16::kOffHead);
     return c->d_policy_packed + bf::kOffHead;
@@ -766,11 +787,7 @@ extern "C" int bf_policy_features_structs(bf_ctx* c, const void* d_structs, size
     if (stride < BF_NODE_EVAL_BYTES) return bf::fail(BF_E_ARG, "bf_policy_features_structs: stride %zu < 82", stride);
     DeviceGuard guard(c->device);
     std::lock_guard<std::mutex> lock(c->policy.mu);
-    if (int r = ensure_boards(&c->policy, n)) return r;
-    if (int r = scratch_acquire(&c->policy, (hipStream_t)stream)) return r;
-    BF_HIP(bf::launch_mailbox_from_structs(d_structs, stride, n, c->policy.d_mailbox, (hipStream_t)stream));
-    BF_HIP(launch_policy_features(c, c->policy.d_mailbox, n, d_x9, (hipStream_t)stream));
-    return scratch_release(&c->policy, (hipStream_t)stream);
+    return features_from_structs(c, d_structs, stride, n, d_x9, (hipStream_t)stream);
 }
 
 extern "C" int bf_policy_scores(bf_ctx* c, const float* d_x9, size_t n_boards, const uint32_t* d_board_index,
@@ -846,7 +863,6 @@ extern "C" int bf_policy_start_structs_host(bf_ctx* c, const void* h_structs, si
     }
     if (m) {
         BF_HIP(hipStreamSynchronize(L->stream));
-        if (int r = ensure_boards(L, m)) return r;
         if (int r = ensure_x9(c, m)) return r;
         // room behind the records for stage 2's move lists (kPolicyMoveRoom moves a board), so that
         // bf_policy_finish_host can stage them while stage 1 still reads the records
@@ -860,11 +876,8 @@ extern "C" int bf_policy_start_structs_host(bf_ctx* c, const void* h_structs, si
             ++k;
         }
         const bool direct = m <= direct_boards() && L->h_in_dev;
-        if (int r = scratch_acquire(L, L->stream)) return r;
         if (!direct) BF_HIP(hipMemcpyAsync(L->d_in, L->h_in, m * kCompact, hipMemcpyHostToDevice, L->stream));
-        BF_HIP(bf::launch_mailbox_from_structs(direct ? L->h_in_dev : L->d_in, kCompact, m, L->d_mailbox, L->stream));
-        BF_HIP(launch_policy_features(c, L->d_mailbox, m, c->d_x9, L->stream));
-        if (int r = scratch_release(L, L->stream)) return r;
+        if (int r = features_from_structs(c, direct ? L->h_in_dev : L->d_in, kCompact, m, c->d_x9, L->stream)) return r;
         c->policy_in_used = rec_bytes;
         c->policy_no_flags = true;   // nothing in this prediction's first stage can raise the device's error flag
     }

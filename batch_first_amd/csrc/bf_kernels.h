@@ -54,5 +54,12 @@ hipError_t launch_eval_t16(const uint8_t* d_mailbox, size_t n, const unsigned ch
                            float* d_debug, hipStream_t stream);
 hipError_t launch_policy_features_t16(const uint8_t* d_mailbox, size_t n, const unsigned char* d_image, float* d_x9,
                                       hipStream_t stream);
+// The same two from node records (88 useful bytes at a 4-byte-aligned address and stride), without a mailbox:
+// the evaluating wave decodes its board's record itself.
+bool t16_takes_records(const void* d_structs, size_t stride);
+hipError_t launch_eval_t16_structs(const void* d_structs, size_t stride, size_t n, const unsigned char* d_image, float* d_scores,
+                                   hipStream_t stream);
+hipError_t launch_policy_features_t16_structs(const void* d_structs, size_t stride, size_t n, const unsigned char* d_image,
+                                              float* d_x9, hipStream_t stream);
 
 }  // namespace bf

@@ -151,9 +151,9 @@ struct WStream {
         if (i == 2) asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" ::"v"(voff), "s"(sbase) : "memory");
         if (i == 3) asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" ::"v"(voff), "s"(sbase) : "memory");
     }
-    __device__ __forceinline__ void prefetch_mailbox(const unsigned char* board_bytes, unsigned lds_dst, int lane) {
+    __device__ __forceinline__ void prefetch_mailbox(const unsigned char* board_bytes, unsigned lds_dst, unsigned voff) {
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2"
-                     ::"s"(lds_dst), "v"((unsigned)(lane & 7) * 4u), "s"(board_bytes) : "memory", "m0");
+                     ::"s"(lds_dst), "v"(voff), "s"(board_bytes) : "memory", "m0");
     }
     __device__ __forceinline__ void prime(const f32x4* stream, f32x4* ring_base, int lane, int wave) {
         typedef __attribute__((address_space(3))) f32x4* lds_ptr;
@@ -436,12 +436,19 @@ __device__ __forceinline__ void dump_tile(float* dst_ch0, int q, int sq, const f
 
 // MODE 0: scores; 1: scores + every intermediate activation (debug); 2: features -- x9 as float32
 // [board][32][64] into `scores`, no head (the move-scoring network).
-template <int MODE>
+// MODE_ + 4: the boards come as node records (bytes 0..81 of each, `src_stride` apart, 4-byte aligned) instead of
+// 4-bit mailboxes: the record -> code step of k_to_mailbox<StructSrc> done by the wave that evaluates the board,
+// one kernel instead of two for a call (a launch and a dependent-launch gap are a tenth of a small call).
+template <int MODE_>
 __global__ __launch_bounds__(THREADS, 1) void k_eval_t16(const uint8_t* __restrict__ mailbox, unsigned n_boards,
                                                           const f32x4* __restrict__ wstream,
                                                           const float* __restrict__ bias,
                                                           const f32x4* __restrict__ headw,
-                                                          float* __restrict__ scores, float* __restrict__ dbg) {
+                                                          float* __restrict__ scores, float* __restrict__ dbg,
+                                                          unsigned src_stride) {
+    constexpr int MODE = MODE_ & 3;
+    constexpr bool RECS = (MODE_ & 4) != 0;
+    constexpr int SRC_DWORDS = RECS ? 22 : 8;   // 88 bytes of a record / 32 bytes of a mailbox
     constexpr bool DBG = MODE == 1;
     __shared__ __attribute__((aligned(16))) Lds lds;
     const int tid = threadIdx.x;
@@ -487,9 +494,9 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_t16(const uint8_t* __restri
     {   // the first board's mailbox directly (every later one is prefetched)
         const unsigned b0 = blockIdx.x * BPB + wave;
         const unsigned bc = b0 < n_boards ? b0 : n_boards - 1;
-        if (lane < 8)
+        if (lane < SRC_DWORDS)
             reinterpret_cast<unsigned*>(lds.next_mailbox[wave])[lane] =
-                reinterpret_cast<const unsigned*>(mailbox + (size_t)bc * kMailboxBytes)[lane];
+                reinterpret_cast<const unsigned*>(mailbox + (size_t)bc * src_stride)[lane];
     }
     lds_order();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -520,8 +527,14 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_t16(const uint8_t* __restri
     lds_order();
     unsigned char* my_entry = region + (((lane >> 3) + GR_ROW0) * GR_COLS + (lane & 7) + GR_COL0) * GR_ENTRY;
     {
-        const unsigned v = lds.next_mailbox[wave][lane >> 1];
-        const unsigned c = (lane & 1) ? (v >> 4) : (v & 15u);
+        unsigned c;
+        if (RECS) {
+            const BoardBits bits = load_board(lds.next_mailbox[wave]);
+            c = (unsigned)square_code(bits, relevance_mask(bits), lane);
+        } else {
+            const unsigned v = lds.next_mailbox[wave][lane >> 1];
+            c = (lane & 1) ? (v >> 4) : (v & 15u);
+        }
         reinterpret_cast<u32x4*>(my_entry)[0] = lds.onehot[c][0];
         reinterpret_cast<u32x4*>(my_entry)[1] = lds.onehot[c][1];
     }
@@ -563,8 +576,9 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_t16(const uint8_t* __restri
             const int kind = kPairOrder.kind[p], a = kPairOrder.a[p], b = kPairOrder.b[p];
             const bf16x8 w = ws.take(g);
             if (g == kPrefetchGroup)
-                ws.prefetch_mailbox(mailbox + (size_t)next_board * kMailboxBytes,
-                                    (unsigned)(uintptr_t)(lds_bytes)lds.next_mailbox[wave], lane);
+                ws.prefetch_mailbox(mailbox + (size_t)next_board * src_stride,
+                                    (unsigned)(uintptr_t)(lds_bytes)lds.next_mailbox[wave],
+                                    (unsigned)(lane < SRC_DWORDS ? lane : SRC_DWORDS - 1) * 4u);
             // the shift of output tile b, two groups ahead of the first 512->128 group that starts from it
             if (p >= 23 && p < 23 + 2 * kOutTiles && ((p - 23) & 1) == 0)
                 seed[(p - 23) >> 1] = *reinterpret_cast<const f32x4*>(&lds.bias2[16 * ((p - 23) >> 1) + 4 * q]);
@@ -810,10 +824,41 @@ hipError_t launch_eval_t16(const uint8_t* d_mailbox, size_t n, const unsigned ch
     if (d_debug)
 #endif
         hipLaunchKernelGGL(t16::k_eval_t16<1>, dim3(blocks), dim3(t16::THREADS), 0, stream, d_mailbox, (unsigned)n, ws, bias, head,
-                           d_scores, d_debug);
+                           d_scores, d_debug, (unsigned)kMailboxBytes);
     else
         hipLaunchKernelGGL(t16::k_eval_t16<0>, dim3(blocks), dim3(t16::THREADS), 0, stream, d_mailbox, (unsigned)n, ws, bias, head,
-                           d_scores, d_debug);
+                           d_scores, d_debug, (unsigned)kMailboxBytes);
+    return hipGetLastError();
+}
+
+bool t16_takes_records(const void* d_structs, size_t stride) {
+    return (reinterpret_cast<uintptr_t>(d_structs) & 3u) == 0 && (stride & 3u) == 0 && stride >= 88 && stride <= 0xFFFFFFFFull;
+}
+
+// Scores straight from node records (t16_takes_records(d_structs, stride) must hold).
+hipError_t launch_eval_t16_structs(const void* d_structs, size_t stride, size_t n, const unsigned char* d_image, float* d_scores,
+                                   hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    unsigned blocks = 0;
+    hipError_t e = t16::grid_blocks(n, &blocks);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(t16::k_eval_t16<4>, dim3(blocks), dim3(t16::THREADS), 0, stream, static_cast<const uint8_t*>(d_structs),
+                       (unsigned)n, reinterpret_cast<const f32x4*>(d_image + t16::kOffStream),
+                       reinterpret_cast<const float*>(d_image + t16::kOffBias),
+                       reinterpret_cast<const f32x4*>(d_image + t16::kOffHead), d_scores, nullptr, (unsigned)stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_policy_features_t16_structs(const void* d_structs, size_t stride, size_t n, const unsigned char* d_image,
+                                              float* d_x9, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    unsigned blocks = 0;
+    hipError_t e = t16::grid_blocks(n, &blocks);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(t16::k_eval_t16<6>, dim3(blocks), dim3(t16::THREADS), 0, stream, static_cast<const uint8_t*>(d_structs),
+                       (unsigned)n, reinterpret_cast<const f32x4*>(d_image + t16::kOffStream),
+                       reinterpret_cast<const float*>(d_image + t16::kOffBias),
+                       reinterpret_cast<const f32x4*>(d_image + t16::kOffHead), d_x9, nullptr, (unsigned)stride);
     return hipGetLastError();
 }
 
@@ -826,7 +871,7 @@ hipError_t launch_policy_features_t16(const uint8_t* d_mailbox, size_t n, const 
     hipLaunchKernelGGL(t16::k_eval_t16<2>, dim3(blocks), dim3(t16::THREADS), 0, stream, d_mailbox, (unsigned)n,
                        reinterpret_cast<const f32x4*>(d_image + t16::kOffStream),
                        reinterpret_cast<const float*>(d_image + t16::kOffBias),
-                       reinterpret_cast<const f32x4*>(d_image + t16::kOffHead), d_x9, nullptr);
+                       reinterpret_cast<const f32x4*>(d_image + t16::kOffHead), d_x9, nullptr, (unsigned)kMailboxBytes);
     return hipGetLastError();
 }
 

@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -151,7 +152,9 @@ struct bfs_search {
     std::vector<float> first_score;  // of the nodes score_moves() handled: the score of their best move
     std::vector<size_t> move_base;
     std::vector<EvalRecord> recs, policy_recs;
-    static constexpr size_t kGrain = 64;   // nodes per piece of a parallel loop
+    size_t grain_min = 64;   // fewest nodes per piece of a parallel loop (BFS_GRAIN in the environment: tuning)
+    // pieces of a parallel loop over n nodes: about four per thread, never smaller than grain_min
+    size_t grain(size_t n) const { return std::max(grain_min, n / (4 * (size_t)pool->threads()) + 1); }
 
     // ---- transposition table (transposition_table.py) ------------------------------------
     TTEntry& entry(u64 h) { return tt[h & tt_mask]; }
@@ -351,7 +354,7 @@ struct bfs_search {
             mv_filt.resize(total);
             mv_per.resize(who.size());
             // stage 1 is started on the records alone; the move lists are packed while the GPU runs it
-            pool->for_range(who.size(), 4 * kGrain, [&](size_t b, size_t e) {
+            pool->for_range(who.size(), 4 * grain(who.size()), [&](size_t b, size_t e) {
                 for (size_t i = b; i < e; ++i) to_record(who[i]->b, &policy_recs[i]);
             });
             ++stats.policy_calls;
@@ -359,7 +362,7 @@ struct bfs_search {
             if (cfg.move_start(cfg.move_user, policy_recs.data(), sizeof(EvalRecord), nullptr, policy_recs.size()))
                 return fail("the move-scoring network's start call failed");
             stats.eval_wait_seconds += now() - tw;
-            pool->for_range(who.size(), kGrain, [&](size_t b, size_t e) {
+            pool->for_range(who.size(), grain(who.size()), [&](size_t b, size_t e) {
                 for (size_t i = b; i < e; ++i) {
                     const Node& n = *who[i];
                     mv_per[i] = n.n_moves;
@@ -380,7 +383,7 @@ struct bfs_search {
             for (size_t i = 0; i < total; ++i) scores[i] = total > 1 ? (float)((double)i / (double)(total - 1)) : 0.0f;
         }
         stats.moves_scored += total;
-        pool->for_range(who.size(), kGrain, [&](size_t b, size_t e) {
+        pool->for_range(who.size(), grain(who.size()), [&](size_t b, size_t e) {
             for (size_t i = b; i < e; ++i) {
                 Node& n = *who[i];
                 const float* src = scores + move_base[i];
@@ -466,7 +469,7 @@ struct bfs_search {
         // the arena afterwards: the arena holds live nodes only and nothing in it ever moves.
         if (fresh.size() < n) fresh.resize(n);
         // depth-zero children first, so that the evaluator gets its boards as early as possible
-        pool->for_range(n, kGrain, [&](size_t b, size_t e) {
+        pool->for_range(n, grain(n), [&](size_t b, size_t e) {
             for (size_t j = b; j < e; ++j) {
                 Node& p = nodes[batch[j]];
                 Node& c = fresh[j];
@@ -493,7 +496,7 @@ struct bfs_search {
         if (!to_eval.empty()) {
             recs.resize(to_eval.size());
             eval_scores.resize(to_eval.size());
-            pool->for_range(to_eval.size(), 4 * kGrain, [&](size_t b, size_t e) {
+            pool->for_range(to_eval.size(), 4 * grain(to_eval.size()), [&](size_t b, size_t e) {
                 for (size_t k = b; k < e; ++k) to_record(fresh[to_eval[k]].b, &recs[k]);
             });
             stats.boards_evaluated += to_eval.size();
@@ -503,7 +506,7 @@ struct bfs_search {
         }
         t1 = now(); stats.expand_seconds += t1 - t0; t0 = t1;
         // meanwhile: the other children (draws, table hits, mates, move generation) and their move scores
-        pool->for_range(n, kGrain, [&](size_t b, size_t e) {
+        pool->for_range(n, grain(n), [&](size_t b, size_t e) {
             for (size_t j = b; j < e; ++j) {
                 Node& c = fresh[j];
                 if (c.depth != 0) flags[j] = settle(c) ? 2 : 0;
@@ -557,7 +560,7 @@ struct bfs_search {
             return fail("search arena would exceed its limit of %zu nodes (bfs_config.max_nodes)", max_nodes);
         nodes.resize(base + kept.size());
         stats.arena_peak = std::max<uint64_t>(stats.arena_peak, nodes.size());
-        pool->for_range(kept.size(), kGrain, [&](size_t b, size_t e) {
+        pool->for_range(kept.size(), grain(kept.size()), [&](size_t b, size_t e) {
             for (size_t i = b; i < e; ++i) {
                 const Node& src = fresh[kept[i]];
                 Node& dst = nodes[base + i];
@@ -911,6 +914,7 @@ extern "C" int bfs_search_create(bfs_search** out, const bfs_config* cfg) {
         return fail("bfs_search_create: could not start the evaluation thread");
     }
     s->cfg.threads = s->pool->threads();
+    if (const char* g = std::getenv("BFS_GRAIN")) s->grain_min = std::max<size_t>(1, std::strtoull(g, nullptr, 10));
     s->tt_mask = ((u64)1 << cfg->tt_bits) - 1;
     *out = s;
     return 0;

@@ -134,6 +134,39 @@ def test_bf16_entry_points_agree_and_are_deterministic(ctx16, predictor16, golde
     assert a[3] == a[4]   # mirrored reference FENs (code_testing.py:36-37)
 
 
+def test_records_decoded_inside_the_kernel_equal_the_two_kernel_form(weights, golden, monkeypatch):
+    """A bf16 context hands 4-byte-aligned records straight to the evaluation kernel (one launch a call); 806-byte
+    reference records (unaligned) and a context created under BF_T16_TWO_KERNELS=1 go through k_to_mailbox first.
+    All three give the same bits, for whole batches, odd sizes and through the host entry point."""
+    import torch
+    from batch_first_amd import ops
+    monkeypatch.setenv("BF_T16_TWO_KERNELS", "1")
+    two = ops.DeviceContext(weights, device=0, dtype="bf16")
+    monkeypatch.delenv("BF_T16_TWO_KERNELS")
+    one = ops.DeviceContext(weights, device=0, dtype="bf16")
+    try:
+        structs806 = P.test_set(1024, seed=0)
+        assert structs806.dtype.itemsize == 806
+        compact = P.to_compact(structs806)
+        r88 = ops.records_to_tensor(compact, torch.device("cuda", 0))
+        r806 = ops.records_to_tensor(structs806, torch.device("cuda", 0))
+        assert r88.shape[1] == 88 and r806.shape[1] == 806
+        want = torch.ops.batchfirst.eval_structs(two.handle, r88).cpu().numpy()
+        for n in (1024, 1023, 5, 1):
+            a = torch.ops.batchfirst.eval_structs(one.handle, r88[:n].contiguous()).cpu().numpy()
+            b = torch.ops.batchfirst.eval_structs(one.handle, r806[:n].contiguous()).cpu().numpy()
+            assert np.array_equal(a.view(np.uint32), want[:n].view(np.uint32)), n
+            assert np.array_equal(b.view(np.uint32), want[:n].view(np.uint32)), n
+        # a view that starts 2 bytes into a record row is not 4-byte aligned: falls back, same scores
+        shifted = torch.zeros(1024 * 88 + 2, dtype=torch.uint8, device="cuda")
+        shifted[2:] = r88.reshape(-1)
+        c = torch.ops.batchfirst.eval_structs(one.handle, shifted[2:].view(1024, 88)).cpu().numpy()
+        assert np.array_equal(c.view(np.uint32), want.view(np.uint32))
+    finally:
+        one.close()
+        two.close()
+
+
 @pytest.fixture(scope="module")
 def siblings():
     import os
