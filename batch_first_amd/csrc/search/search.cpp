@@ -146,7 +146,11 @@ struct bfs_search {
     // buffers of iterate(), kept between calls
     std::vector<float> parent_next_score, eval_scores, move_scores_buf;
     std::vector<uint8_t> flags, mv_from, mv_filt, mv_per;
-    std::vector<int> to_eval, kept;
+    std::vector<int> to_eval, kept, cand;
+    std::vector<unsigned> bin_idx;
+    std::vector<uint8_t> live;
+    std::vector<int8_t> tt_index;    // of the nodes being scored: index of the table move in their move list, or -1
+    std::unique_ptr<Lane> policy_lane;   // the blocking half of the move-scoring call, beside the tree update
     std::vector<Node*> to_score;
     std::vector<Node> fresh;         // the children of the batch in flight; the ones that stay open move to the arena
     std::vector<float> first_score;  // of the nodes score_moves() handled: the score of their best move
@@ -322,21 +326,36 @@ struct bfs_search {
         return true;
     }
 
-    // A legal move stored in the table goes first (has_legal_tt_move, :262-281).
-    void apply_tt_move(Node& n) {
-        const TTEntry& e = entry(n.b.hash);
-        if (e.depth == kNoEntry || e.hash != n.b.hash || e.move.from == 255) return;
+    // A legal move stored in the table goes first (has_legal_tt_move, :262-281): its index in the node's moves, or -1.
+    int table_move_index(const Node& n) const {
+        const TTEntry& e = tt[n.b.hash & tt_mask];
+        if (e.depth == kNoEntry || e.hash != n.b.hash || e.move.from == 255) return -1;
         for (int i = 0; i < n.n_moves; ++i)
-            if (n.moves[i] == e.move) {
-                n.move_scores[i] = g_tt_move_score;
-                return;
-            }
+            if (n.moves[i] == e.move) return i;
+        return -1;
     }
 
-    // Scores the moves of the listed nodes with the move-scoring network (start_move_scoring :164-180,
-    // get_move_from_and_filter_squares_and_sizes :485-527) or with the reference's fake, puts a legal table move
-    // first and picks each node's first move (first_score[i]).
-    int score_moves(const std::vector<Node*>& who) {
+    // Move scores of the listed nodes, in two halves so that the tree update can run between them while the GPU
+    // works (start_move_scoring :164-180, get_move_from_and_filter_squares_and_sizes :485-527; the reference's fake
+    // when no network is given).
+    // score_begin: packs records and move lists, starts stage 1, hands stage 2 (which blocks until the GPU is done) to
+    // the policy lane, and looks up each node's table move NOW, i.e. in the table as it is before this batch's
+    // updates, which is when the reference looks (has_legal_tt_move at child creation, :262-281).
+    struct FinishCall {
+        bfs_search* s;
+        size_t boards, total;
+    };
+    static int run_finish(void* arg) {
+        FinishCall* c = static_cast<FinishCall*>(arg);
+        bfs_search* s = c->s;
+        return s->cfg.move_finish(s->cfg.move_user, s->mv_from.data(), s->mv_filt.data(), s->mv_per.data(), c->boards, c->total,
+                                  s->move_scores_buf.data());
+    }
+    FinishCall finish_call{};
+    bool finish_pending = false;
+
+    int score_begin(const std::vector<Node*>& who) {
+        finish_pending = false;
         if (who.empty()) return 0;
         move_base.resize(who.size() + 1);
         size_t total = 0;
@@ -347,6 +366,7 @@ struct bfs_search {
         move_base[who.size()] = total;
         move_scores_buf.resize(total);
         first_score.resize(who.size());
+        tt_index.resize(who.size());
         float* scores = move_scores_buf.data();
         if (cfg.move_start && cfg.move_finish) {
             policy_recs.resize(who.size());
@@ -358,37 +378,56 @@ struct bfs_search {
                 for (size_t i = b; i < e; ++i) to_record(who[i]->b, &policy_recs[i]);
             });
             ++stats.policy_calls;
-            double tw = now();
+            const double tw = now();
             if (cfg.move_start(cfg.move_user, policy_recs.data(), sizeof(EvalRecord), nullptr, policy_recs.size()))
                 return fail("the move-scoring network's start call failed");
-            stats.eval_wait_seconds += now() - tw;
-            pool->for_range(who.size(), grain(who.size()), [&](size_t b, size_t e) {
-                for (size_t i = b; i < e; ++i) {
-                    const Node& n = *who[i];
-                    mv_per[i] = n.n_moves;
-                    const int flip = n.b.turn ? 0 : 56;  // SQUARES_180 for black: the mover's frame
-                    size_t m = move_base[i];
-                    for (int k = 0; k < n.n_moves; ++k, ++m) {
-                        const int f = n.moves[k].from ^ flip, t = n.moves[k].to ^ flip;
-                        mv_from[m] = (uint8_t)f;
-                        mv_filt[m] = g_filter[f][t][n.moves[k].promo < 6 ? n.moves[k].promo : 0];
-                    }
-                }
-            });
-            tw = now();
-            if (cfg.move_finish(cfg.move_user, mv_from.data(), mv_filt.data(), mv_per.data(), mv_per.size(), total, scores))
-                return fail("the move-scoring network's finish call failed");
             stats.eval_wait_seconds += now() - tw;
         } else {
             for (size_t i = 0; i < total; ++i) scores[i] = total > 1 ? (float)((double)i / (double)(total - 1)) : 0.0f;
         }
+        const bool net = cfg.move_start && cfg.move_finish;
+        pool->for_range(who.size(), grain(who.size()), [&](size_t b, size_t e) {
+            for (size_t i = b; i < e; ++i) {
+                const Node& n = *who[i];
+                tt_index[i] = (int8_t)table_move_index(n);
+                if (!net) continue;
+                mv_per[i] = n.n_moves;
+                const int flip = n.b.turn ? 0 : 56;  // SQUARES_180 for black: the mover's frame
+                size_t m = move_base[i];
+                for (int k = 0; k < n.n_moves; ++k, ++m) {
+                    const int f = n.moves[k].from ^ flip, t = n.moves[k].to ^ flip;
+                    mv_from[m] = (uint8_t)f;
+                    mv_filt[m] = g_filter[f][t][n.moves[k].promo < 6 ? n.moves[k].promo : 0];
+                }
+            }
+        });
+        if (net) {
+            finish_call = FinishCall{this, who.size(), total};
+            policy_lane->submit(&run_finish, &finish_call);
+            finish_pending = true;
+        }
         stats.moves_scored += total;
+        return 0;
+    }
+
+    // score_end: waits for stage 2, hands every node its scores, puts its table move first and picks its first move
+    // (first_score[i]).
+    int score_end(const std::vector<Node*>& who) {
+        if (finish_pending) {
+            finish_pending = false;
+            const double tw = now();
+            const int rc = policy_lane->wait();
+            stats.eval_wait_seconds += now() - tw;
+            if (rc) return fail("the move-scoring network's finish call failed");
+        }
+        if (who.empty()) return 0;
+        const float* scores = move_scores_buf.data();
         pool->for_range(who.size(), grain(who.size()), [&](size_t b, size_t e) {
             for (size_t i = b; i < e; ++i) {
                 Node& n = *who[i];
                 const float* src = scores + move_base[i];
                 for (int k = 0; k < n.n_moves; ++k) n.move_scores[k] = src[k];
-                apply_tt_move(n);
+                if (tt_index[i] >= 0) n.move_scores[tt_index[i]] = g_tt_move_score;
                 first_score[i] = next_best_move(n);   // the node is ready for the open list
             }
         });
@@ -413,29 +452,57 @@ struct bfs_search {
         in_bins = 0;
     }
 
+    // Appends to `batch` those of cand[from..) that are still worth expanding, in order; the checks (a walk up
+    // the ancestors, read-only) run on the pool.
+    void keep_live(const std::vector<int>& cand_ids, size_t from, std::vector<int>* batch) {
+        const size_t n = cand_ids.size() - from;
+        live.resize(n);
+        pool->for_range(n, grain(n), [&](size_t b, size_t e) {
+            for (size_t i = b; i < e; ++i) live[i] = should_not_terminate(cand_ids[from + i]) ? 1 : 0;
+        });
+        for (size_t i = 0; i < n; ++i)
+            if (live[i]) batch->push_back(cand_ids[from + i]);
+    }
+
+    // insert_nodes + get_batch (global_open_priority_nodes.py:73-121,143-177).  Nodes leave the bins in the same order
+    // as one at a time: candidates are popped in rounds of exactly as many as the batch still lacks, so the last one
+    // popped is the one that fills it.
     std::vector<int> insert_and_get_batch(const std::vector<int>& ids, const std::vector<float>& scores) {
         stats.nodes_in += ids.size();
         std::vector<int> batch;
+        cand.clear();
         if (ids.size() + in_bins < cfg.max_batch_size) {
             for (auto& b : bins) {
-                for (auto it = b.rbegin(); it != b.rend(); ++it)
-                    if (should_not_terminate(*it)) batch.push_back(*it);
+                cand.insert(cand.end(), b.rbegin(), b.rend());
                 b.clear();
             }
             in_bins = 0;
-            for (int id : ids)
-                if (should_not_terminate(id)) batch.push_back(id);
+            cand.insert(cand.end(), ids.begin(), ids.end());
+            keep_live(cand, 0, &batch);
         } else {
-            for (size_t i = 0; i < ids.size(); ++i) bins[bin_of(scores[i])].push_back(ids[i]);
+            bin_idx.resize(ids.size());
+            pool->for_range(ids.size(), 4 * grain(ids.size()), [&](size_t b, size_t e) {
+                for (size_t i = b; i < e; ++i) bin_idx[i] = (unsigned)bin_of(scores[i]);
+            });
+            for (size_t i = 0; i < ids.size(); ++i) bins[bin_idx[i]].push_back(ids[i]);
             in_bins += ids.size();
-            for (auto& b : bins) {
-                while (!b.empty() && batch.size() < cfg.max_batch_size) {
-                    const int id = b.back();
+            size_t bin = 0;
+            while (batch.size() < cfg.max_batch_size && in_bins > 0) {
+                const size_t from = cand.size();
+                size_t need = cfg.max_batch_size - batch.size();
+                while (need > 0 && bin < bins.size()) {
+                    auto& b = bins[bin];
+                    if (b.empty()) {
+                        ++bin;
+                        continue;
+                    }
+                    cand.push_back(b.back());
                     b.pop_back();
                     --in_bins;
-                    if (should_not_terminate(id)) batch.push_back(id);
+                    --need;
                 }
-                if (batch.size() == cfg.max_batch_size) break;
+                if (cand.size() == from) break;
+                keep_live(cand, from, &batch);
             }
         }
         stats.nodes_out += batch.size();
@@ -520,18 +587,28 @@ struct bfs_search {
                 kept.push_back((int)j);
             }
         t1 = now(); stats.settle_seconds += t1 - t0; t0 = t1;
-        const int score_rc = score_moves(to_score);
+        const int score_rc = score_begin(to_score);
         t1 = now(); stats.policy_seconds += t1 - t0; t0 = t1;
         const int eval_rc = to_eval.empty() ? 0 : eval_lane->wait();
         t1 = now(); stats.value_wait_seconds += t1 - t0;
         stats.eval_wait_seconds += t1 - t0;
         t0 = t1;
-        if (eval_rc) return fail("the value network's evaluation call failed");
-        if (score_rc) return score_rc;
+        if (eval_rc || score_rc) {
+            if (finish_pending) {   // nothing of this batch may still be running when the call returns
+                (void)policy_lane->wait();
+                finish_pending = false;
+            }
+            return eval_rc ? fail("the value network's evaluation call failed") : score_rc;
+        }
         // update_tree_from_terminating_nodes, :422-453
         size_t e = 0;
         for (size_t j = 0; j < n; ++j) {
             Node& c = fresh[j];
+            if (j + 8 < n) {   // the table lines this loop will touch a few children from now: the child's and its parent's
+                const Node& ahead = fresh[j + 8];
+                __builtin_prefetch(&entry(ahead.b.hash), 1);
+                __builtin_prefetch(&entry(nodes[ahead.parent].b.hash), 1);
+            }
             if (e < to_eval.size() && to_eval[e] == (int)j) {
                 const float s = eval_scores[e++] - cfg.eval_zero_shift;
                 TTEntry& t = entry(c.b.hash);  // add_evaluated_boards_to_tt, transposition_table.py:138-148
@@ -546,6 +623,9 @@ struct bfs_search {
             }
         }
         t1 = now(); stats.update_seconds += t1 - t0; t0 = t1;
+        // the move scores, which the GPU worked on during the update
+        if (int rc = score_end(to_score)) return rc;
+        t1 = now(); stats.policy_seconds += t1 - t0; t0 = t1;
         // parents with moves left go back to the open list, open children join it
         to_insert->clear();
         insert_scores->clear();
@@ -618,7 +698,8 @@ struct bfs_search {
         if (!settle(r)) return 0;
         const double t0 = now();
         to_score.assign(1, &nodes[0]);
-        if (int rc = score_moves(to_score)) return rc;
+        if (int rc = score_begin(to_score)) return rc;
+        if (int rc = score_end(to_score)) return rc;
         stats.policy_seconds += now() - t0;
         return 0;
     }
@@ -905,13 +986,14 @@ extern "C" int bfs_search_create(bfs_search** out, const bfs_config* cfg) {
         s->tt.assign((size_t)1 << cfg->tt_bits, TTEntry());
         s->pool.reset(new Pool(threads));       // runs with the workers it could start
         s->eval_lane.reset(new Lane());
+        s->policy_lane.reset(new Lane());
     } catch (const std::exception& e) {
         delete s;
         return fail("bfs_search_create: %s", e.what());
     }
-    if (!s->eval_lane->ok()) {
+    if (!s->eval_lane->ok() || !s->policy_lane->ok()) {
         delete s;
-        return fail("bfs_search_create: could not start the evaluation thread");
+        return fail("bfs_search_create: could not start the evaluation threads");
     }
     s->cfg.threads = s->pool->threads();
     if (const char* g = std::getenv("BFS_GRAIN")) s->grain_min = std::max<size_t>(1, std::strtoull(g, nullptr, 10));

@@ -81,9 +81,20 @@ def cpu_baseline(budget_s=12.0):
         dt = time.perf_counter() - t0
         if dt >= budget_s or done >= 256 * chunk:
             break
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return {"value": done / dt, "unit": "boards/s", "cores": cores, "kind": "port",
             "sample": "%d boards in chunks of %d: oracle C encoder (1 thread) + torch-CPU fp32 graph (%d threads), %.1f s"
-                      % (done, chunk, cores, dt)}
+                      % (done, chunk, cores, dt),
+            "label": "CPU restatement of the reference graph (the reference's TensorFlow + Numba path cannot run here)",
+            "cpu_model": cpu_model, "torch": torch.__version__}
 
 
 def main():

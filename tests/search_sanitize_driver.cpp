@@ -3,12 +3,20 @@
 #include <cstdio>
 #include <vector>
 #include "search.h"
+// a stand-in for the move-scoring network, so that the policy lane runs too: scores from the move's squares
+static int fake_start(void*, const void*, size_t, const uint8_t*, size_t) { return 0; }
+static int fake_finish(void*, const uint8_t* from, const uint8_t* filt, const uint8_t*, size_t, size_t n_moves, float* scores) {
+    for (size_t i = 0; i < n_moves; ++i) scores[i] = (float)((from[i] * 73 + filt[i]) % 97) / 97.0f;
+    return 0;
+}
+
 int main() {
     std::vector<float> edges(1000);
     for (int i = 0; i < 1000; ++i) edges[i] = -4000.f + 8000.f * i / 999.f;
     bfs_config cfg{};
     cfg.max_batch_size = 256; cfg.tt_bits = 16; cfg.bin_edges = edges.data(); cfg.n_bin_edges = edges.size();
     cfg.board_eval = bfs_material_eval; cfg.threads = 4;
+    cfg.move_start = fake_start; cfg.move_finish = fake_finish;
     const char* fens[] = {"rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1",
                           "r3k2r/p1ppqpb1/bn2pnp1/3PN3/1p2P3/2N2Q1p/PPPBBPPP/R3K2R w KQkq - 0 1"};
     for (const char* fen : fens) {
