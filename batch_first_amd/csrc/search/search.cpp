@@ -16,6 +16,8 @@
 #include <string>
 #include <vector>
 
+#include <sys/mman.h>
+
 #include "board.h"
 #include "threads.h"
 
@@ -110,18 +112,30 @@ public:
     Arena(const Arena&) = delete;
     Arena& operator=(const Arena&) = delete;
     ~Arena() {
-        for (Node* b : blocks_) ::operator delete(b);
+        for (Node* b : blocks_) std::free(b);
     }
     size_t size() const { return size_; }
     Node& operator[](size_t i) { return blocks_[i >> kShift][i & (kBlock - 1)]; }
     const Node& operator[](size_t i) const { return blocks_[i >> kShift][i & (kBlock - 1)]; }
     void clear() { size_ = 0; }        // blocks are kept for the next search
     void resize(size_t n) {            // may throw std::bad_alloc; new nodes are uninitialised
-        while (blocks_.size() * kBlock < n) blocks_.push_back(static_cast<Node*>(::operator new(kBlock * sizeof(Node))));
+        while (blocks_.size() * kBlock < n) blocks_.push_back(new_block());
         size_ = n;
     }
 
 private:
+    // 2 MiB-aligned and advised as huge pages: a block is touched for the first time while the search runs, and
+    // with 4 KiB pages that is 3 300 page faults a block
+    static Node* new_block() {
+        constexpr size_t kHuge = (size_t)2 << 20;
+        const size_t bytes = (kBlock * sizeof(Node) + kHuge - 1) / kHuge * kHuge;
+        void* p = std::aligned_alloc(kHuge, bytes);
+        if (!p) throw std::bad_alloc();
+#ifdef MADV_HUGEPAGE
+        (void)madvise(p, bytes, MADV_HUGEPAGE);
+#endif
+        return static_cast<Node*>(p);
+    }
     std::vector<Node*> blocks_;
     size_t size_ = 0;
 };
@@ -538,6 +552,12 @@ struct bfs_search {
         // depth-zero children first, so that the evaluator gets its boards as early as possible
         pool->for_range(n, grain(n), [&](size_t b, size_t e) {
             for (size_t j = b; j < e; ++j) {
+                if (j + 6 < e) {   // parents lie anywhere in an arena of gigabytes: ask for their lines a few nodes ahead
+                    const char* q = reinterpret_cast<const char*>(&nodes[batch[j + 6]]);
+                    for (size_t off : {(size_t)0, (size_t)64, offsetof(Node, moves), offsetof(Node, moves) + 64,
+                                       offsetof(Node, move_scores), offsetof(Node, move_scores) + 64, offsetof(Node, move_scores) + 128})
+                        __builtin_prefetch(q + off, 1);
+                }
                 Node& p = nodes[batch[j]];
                 Node& c = fresh[j];
                 const Move m = p.moves[p.next_move_index];
@@ -553,6 +573,11 @@ struct bfs_search {
                 c.next_move_index = kNoMoreMoves;
                 c.children_left = 0;
                 c.prev_move = m;
+            }
+            // second pass over the piece: the checks of the depth-0 children, their table lines asked for ahead
+            for (size_t j = b; j < e; ++j) {
+                if (j + 6 < e) __builtin_prefetch(&tt[fresh[j + 6].b.hash & tt_mask]);
+                Node& c = fresh[j];
                 flags[j] = (c.depth == 0 && settle(c)) ? 1 : 0;
             }
         });
@@ -575,6 +600,7 @@ struct bfs_search {
         // meanwhile: the other children (draws, table hits, mates, move generation) and their move scores
         pool->for_range(n, grain(n), [&](size_t b, size_t e) {
             for (size_t j = b; j < e; ++j) {
+                if (j + 6 < e) __builtin_prefetch(&tt[fresh[j + 6].b.hash & tt_mask]);
                 Node& c = fresh[j];
                 if (c.depth != 0) flags[j] = settle(c) ? 2 : 0;
             }
