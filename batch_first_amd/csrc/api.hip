@@ -9,6 +9,7 @@
 
 #include "../../include/batchfirst.h"
 #include "bf_internal.h"
+#include "bf_encode.h"
 #include "bf_kernels.h"
 #include "bf_layout.h"
 #include "bf_layout_bf16.h"
@@ -162,6 +163,80 @@ int scratch_release(Lane* c, hipStream_t s) {
     return BF_OK;
 }
 
+// calls of at most this many boards / moves use the direct path (Lane::h_in_dev); BF_DIRECT_BOARDS=0 turns it off
+size_t direct_boards() {
+    static const size_t v = [] {
+        const char* e = std::getenv("BF_DIRECT_BOARDS");
+        return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)2048;
+    }();
+    return v;
+}
+constexpr size_t kDirectMovesPerBoard = 64;
+constexpr size_t kHostOffsetBoards = 4096;   // wire-format host calls up to this size skip the device scan (see bf_eval_wire_host)
+
+// Wire format into a lane's pinned staging with every board's nibble offset beside it (the caller has checked that
+// the stream's length matches the popcounts): occupied u64[n] | offsets u32[n] | zero bases u32[blocks] | nibble bytes.
+struct StagedWire {
+    size_t off_offsets = 0, off_bases = 0, off_pf = 0, bytes = 0;
+};
+StagedWire wire_layout(size_t n, size_t n_bytes) {
+    StagedWire w;
+    w.off_offsets = n * sizeof(uint64_t);
+    w.off_bases = w.off_offsets + n * sizeof(uint32_t);
+    w.off_pf = (w.off_bases + bf::scan_blocks_for(n) * sizeof(uint32_t) + 15) & ~(size_t)15;
+    w.bytes = w.off_pf + n_bytes;
+    return w;
+}
+void stage_wire(unsigned char* h_in, const StagedWire& w, const uint8_t* h_pf, size_t n_bytes, const uint64_t* h_occ, size_t n,
+                unsigned start_nibble) {
+    std::memcpy(h_in, h_occ, n * sizeof(uint64_t));
+    uint32_t* off = reinterpret_cast<uint32_t*>(h_in + w.off_offsets);
+    uint32_t run = 0;
+    for (size_t i = 0; i < n; ++i) {
+        off[i] = run;
+        run += (uint32_t)__builtin_popcountll(h_occ[i]);
+    }
+    (void)start_nibble;   // the kernel adds it
+    std::memset(h_in + w.off_bases, 0, w.off_pf - w.off_bases);
+    if (n_bytes) std::memcpy(h_in + w.off_pf, h_pf, n_bytes);
+}
+
+// Wire format -> mailboxes of lane L on its own stream, staged through its pinned buffer (caller holds L->mu, has
+// checked the stream's length against the popcounts and called ensure_boards + scratch_acquire).
+// Small calls: the boards' nibble offsets are added up here, on the host, so that the two scan kernels are not
+// needed, and (may_direct) the kernel reads the pinned staging itself: launches and copies are what a small call
+// costs.  Large calls keep the device scan, which beats one host thread from a few thousand boards on.
+// *direct: the staging was not copied to the device; *staged: bytes of staging in use.
+int wire_to_mailbox(Lane* L, const uint8_t* h_pf, size_t n_bytes, const uint64_t* h_occ, size_t n, unsigned start_nibble,
+                    size_t n_scores, bool may_direct, bool* direct, size_t* staged) {
+    const bool host_offsets = n <= kHostOffsetBoards;
+    *direct = host_offsets && may_direct && n <= direct_boards() && L->h_in_dev != nullptr;
+    if (host_offsets) {
+        const StagedWire w = wire_layout(n, n_bytes);
+        if (int r = ensure_staging(L, w.bytes + 16, n_scores)) return r;
+        *direct = *direct && L->h_in_dev != nullptr;   // (the buffer may just have been regrown)
+        stage_wire(L->h_in, w, h_pf, n_bytes, h_occ, n, start_nibble);
+        const unsigned char* in = *direct ? L->h_in_dev : L->d_in;
+        if (!*direct) BF_HIP(hipMemcpyAsync(L->d_in, L->h_in, w.bytes, hipMemcpyHostToDevice, L->stream));
+        BF_HIP(bf::launch_mailbox_from_wire_offsets(in + w.off_pf, n_bytes, reinterpret_cast<const uint64_t*>(in), n,
+                                                    reinterpret_cast<const unsigned*>(in + w.off_offsets),
+                                                    reinterpret_cast<const unsigned*>(in + w.off_bases), L->d_err,
+                                                    L->d_mailbox, L->stream, start_nibble));
+        *staged = w.bytes;
+    } else {
+        const size_t occ_bytes = n * sizeof(uint64_t);
+        const size_t pf_off = (occ_bytes + 15) & ~(size_t)15;
+        if (int r = ensure_staging(L, pf_off + n_bytes + 16, n_scores)) return r;
+        std::memcpy(L->h_in, h_occ, occ_bytes);
+        if (n_bytes) std::memcpy(L->h_in + pf_off, h_pf, n_bytes);
+        BF_HIP(hipMemcpyAsync(L->d_in, L->h_in, pf_off + n_bytes, hipMemcpyHostToDevice, L->stream));
+        BF_HIP(bf::launch_mailbox_from_wire(L->d_in + pf_off, n_bytes, reinterpret_cast<const uint64_t*>(L->d_in), n,
+                                            workspace(L), L->d_mailbox, L->stream, start_nibble));
+        *staged = pf_off + n_bytes;
+    }
+    return BF_OK;
+}
+
 // Records -> scores (value network) on stream `s`.  `L` = the lane whose mailbox scratch the two-kernel form uses.
 int eval_from_structs(bf_ctx* c, const void* d_structs, size_t stride, size_t n, float* d_scores, hipStream_t s) {
     if (c->precision == BF_PRECISION_BF16 && !c->tiles32 && !c->two_kernels && bf::t16_takes_records(d_structs, stride)) {
@@ -192,15 +267,6 @@ int read_err_flag(Lane* c, hipStream_t s) {
 }
 
 constexpr size_t kMaxBoards = (size_t)1 << 26;
-// calls of at most this many boards / moves use the direct path (Lane::h_in_dev); BF_DIRECT_BOARDS=0 turns it off
-size_t direct_boards() {
-    static const size_t v = [] {
-        const char* e = std::getenv("BF_DIRECT_BOARDS");
-        return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)2048;
-    }();
-    return v;
-}
-constexpr size_t kDirectMovesPerBoard = 64;
 constexpr size_t kPolicyMoveRoom = 64;   // moves a board that bf_policy_start_structs_host reserves staging for
 
 // ---- scratch of the allocation-free entry point (bf_eval_structs_noalloc) -----------------------
@@ -470,18 +536,14 @@ extern "C" int bf_eval_wire_host(bf_ctx* c, const uint8_t* h_pf, size_t n_bytes,
     DeviceGuard guard(c->device);
     std::lock_guard<std::mutex> lock(c->mu);
     if (int r = ensure_boards(c, n)) return r;
-    const size_t occ_bytes = n * sizeof(uint64_t);
-    const size_t pf_off = (occ_bytes + 15) & ~(size_t)15;
-    if (int r = ensure_staging(c, pf_off + n_bytes + 16, n)) return r;
-    std::memcpy(c->h_in, h_occ, occ_bytes);
-    if (n_bytes) std::memcpy(c->h_in + pf_off, h_pf, n_bytes);
     if (int r = scratch_acquire(c, c->stream)) return r;
-    BF_HIP(hipMemcpyAsync(c->d_in, c->h_in, pf_off + n_bytes, hipMemcpyHostToDevice, c->stream));
-    BF_HIP(bf::launch_mailbox_from_wire(c->d_in + pf_off, n_bytes, reinterpret_cast<const uint64_t*>(c->d_in), n,
-                                        workspace(c), c->d_mailbox, c->stream));
-    BF_HIP(launch_eval(c, c->d_mailbox, n, c->d_scores, nullptr, c->stream));
+    bool direct = false;
+    size_t staged = 0;
+    if (int r = wire_to_mailbox(c, h_pf, n_bytes, h_occ, n, 0, n, c->h_scores_dev != nullptr, &direct, &staged)) return r;
+    direct = direct && c->h_scores_dev != nullptr;
+    BF_HIP(launch_eval(c, c->d_mailbox, n, direct ? c->h_scores_dev : c->d_scores, nullptr, c->stream));
     if (int r = scratch_release(c, c->stream)) return r;
-    BF_HIP(hipMemcpyAsync(c->h_scores, c->d_scores, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (!direct) BF_HIP(hipMemcpyAsync(c->h_scores, c->d_scores, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     if (int r = read_err_flag(c, c->stream)) return r;
     std::memcpy(h_scores, c->h_scores, n * sizeof(float));
     return BF_OK;
@@ -571,15 +633,10 @@ int start_wire_shard(bf_ctx* c, const uint8_t* h_pf, size_t n_bytes, unsigned st
     DeviceGuard guard(c->device);
     if (!guard.ok) return bf::fail(BF_E_HIP, "hipSetDevice(%d) failed", c->device);
     if (int r = ensure_boards(c, n)) return r;
-    const size_t occ_bytes = n * sizeof(uint64_t);
-    const size_t pf_off = (occ_bytes + 15) & ~(size_t)15;
-    if (int r = ensure_staging(c, pf_off + n_bytes + 16, n)) return r;
-    std::memcpy(c->h_in, h_occ, occ_bytes);
-    if (n_bytes) std::memcpy(c->h_in + pf_off, h_pf, n_bytes);
     if (int r = scratch_acquire(c, c->stream)) return r;
-    BF_HIP(hipMemcpyAsync(c->d_in, c->h_in, pf_off + n_bytes, hipMemcpyHostToDevice, c->stream));
-    BF_HIP(bf::launch_mailbox_from_wire(c->d_in + pf_off, n_bytes, reinterpret_cast<const uint64_t*>(c->d_in), n,
-                                        workspace(c), c->d_mailbox, c->stream, start_nibble));
+    bool direct = false;
+    size_t staged = 0;
+    if (int r = wire_to_mailbox(c, h_pf, n_bytes, h_occ, n, start_nibble, n, false, &direct, &staged)) return r;
     BF_HIP(launch_eval(c, c->d_mailbox, n, c->d_scores, nullptr, c->stream));
     if (int r = scratch_release(c, c->stream)) return r;
     BF_HIP(hipMemcpyAsync(c->h_scores, c->d_scores, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -827,18 +884,13 @@ extern "C" int bf_policy_start_wire_host(bf_ctx* c, const uint8_t* h_pf, size_t 
         BF_HIP(hipStreamSynchronize(L->stream));
         if (int r = ensure_boards(L, n)) return r;
         if (int r = ensure_x9(c, n)) return r;
-        const size_t occ_bytes = n * sizeof(uint64_t);
-        const size_t pf_off = (occ_bytes + 15) & ~(size_t)15;
-        if (int r = ensure_staging(L, pf_off + n_bytes + 16, 1)) return r;
-        std::memcpy(L->h_in, h_occ, occ_bytes);
-        if (n_bytes) std::memcpy(L->h_in + pf_off, h_pf, n_bytes);
         if (int r = scratch_acquire(L, L->stream)) return r;
-        BF_HIP(hipMemcpyAsync(L->d_in, L->h_in, pf_off + n_bytes, hipMemcpyHostToDevice, L->stream));
-        BF_HIP(bf::launch_mailbox_from_wire(L->d_in + pf_off, n_bytes, reinterpret_cast<const uint64_t*>(L->d_in), n,
-                                            workspace(L), L->d_mailbox, L->stream));
+        bool direct = false;
+        size_t staged = 0;
+        if (int r = wire_to_mailbox(L, h_pf, n_bytes, h_occ, n, 0, 1, true, &direct, &staged)) return r;
         BF_HIP(launch_policy_features(c, L->d_mailbox, n, c->d_x9, L->stream));
         if (int r = scratch_release(L, L->stream)) return r;
-        c->policy_in_used = (pf_off + n_bytes + 255) & ~(size_t)255;
+        c->policy_in_used = (staged + 255) & ~(size_t)255;
         c->policy_no_flags = false;  // the wire decoder reports malformed input through the flag
     }
     c->policy_boards = n;

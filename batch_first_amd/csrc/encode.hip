@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include "bf_device.h"
+#include "bf_encode.h"
 #include "bf_kernels.h"
 
 namespace bf {
@@ -190,6 +191,18 @@ hipError_t launch_mailbox_from_wire(const uint8_t* d_nib, size_t n_bytes, const 
     hipError_t e = scan_offsets(d_occ, n, n_bytes, start_nibble, ws, stream);
     if (e != hipSuccess) return e;
     WireSrc src{d_nib, (unsigned long long)n_bytes, d_occ, ws.local_off, ws.block_total, ws.err_flag, start_nibble};
+    hipLaunchKernelGGL(k_to_mailbox<WireSrc>, dim3(blocks_for(n, 4)), dim3(256), 0, stream, src, (unsigned)n, d_mailbox);
+    return hipGetLastError();
+}
+
+// The same with every board's nibble offset already known (the host entry points add up the popcounts anyway to
+// check the stream's length): no scan kernels.  d_offsets[b] = codes of the boards before b; d_zero_bases = zeros,
+// one per kScanBoardsPerBlock boards (the per-block bases of the device scan, which the offsets here include).
+hipError_t launch_mailbox_from_wire_offsets(const uint8_t* d_nib, size_t n_bytes, const uint64_t* d_occ, size_t n,
+                                            const unsigned* d_offsets, const unsigned* d_zero_bases, int* d_err,
+                                            uint8_t* d_mailbox, hipStream_t stream, unsigned start_nibble) {
+    if (n == 0) return hipSuccess;
+    WireSrc src{d_nib, (unsigned long long)n_bytes, d_occ, d_offsets, d_zero_bases, d_err, start_nibble};
     hipLaunchKernelGGL(k_to_mailbox<WireSrc>, dim3(blocks_for(n, 4)), dim3(256), 0, stream, src, (unsigned)n, d_mailbox);
     return hipGetLastError();
 }
