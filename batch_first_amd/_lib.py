@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("BATCHFIRST_LIB") or os.path.join(_HERE, "libbatchfirs
 BF_OK, BF_E_ARG, BF_E_HIP, BF_E_FORMAT, BF_E_NOGPU = 0, -1, -2, -3, -4
 BF_PRECISION_F32, BF_PRECISION_BF16 = 0, 1
 BF_NOALLOC_MAX_BOARDS = 262144
+BF_SPLIT_BOARDS_DEFAULT = 512
 PRECISIONS = {"f32": BF_PRECISION_F32, "fp32": BF_PRECISION_F32, "float32": BF_PRECISION_F32,
               "bf16": BF_PRECISION_BF16, "bfloat16": BF_PRECISION_BF16}
 
@@ -34,6 +35,7 @@ SIGNATURES = {
     "bf_ctx_create": (_int, [_c.POINTER(_vp), _int, _vp, _sz]),
     "bf_ctx_create_ex": (_int, [_c.POINTER(_vp), _int, _vp, _sz, _int]),
     "bf_ctx_precision": (_int, [_vp]),
+    "bf_set_split_boards": (_sz, [_sz]),
     "bf_ctx_destroy": (None, [_vp]),
     "bf_eval_wire": (_int, [_vp, _vp, _sz, _vp, _sz, _vp, _vp]),
     "bf_eval_structs": (_int, [_vp, _vp, _sz, _sz, _vp, _vp]),

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -14,6 +15,7 @@
 #include "bf_layout.h"
 #include "bf_layout_bf16.h"
 #include "bf_layout_t16.h"
+#include "bf_split.h"
 
 #define BF_HIP(call)                                                                         \
     do {                                                                                     \
@@ -141,8 +143,21 @@ int ensure_staging(Lane* c, size_t in_bytes, size_t n_scores) {
     return BF_OK;
 }
 
+// bf16 calls of at most this many boards run the one-board-per-workgroup kernel (eval_t16s.hip): bit-identical
+// scores, a third of the time while the boards are fewer than the workgroups the chip holds twice over
+// (bf_set_split_boards; BF_SPLIT_BOARDS in the environment sets the start value, 0 turns it off).
+std::atomic<size_t> g_split_boards{[] {
+    const char* e = std::getenv("BF_SPLIT_BOARDS");
+    return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)BF_SPLIT_BOARDS_DEFAULT;
+}()};
+bool use_split(const bf_ctx* c, size_t n) {
+    return c->precision == BF_PRECISION_BF16 && !c->tiles32 && n <= g_split_boards.load(std::memory_order_relaxed);
+}
+
 // The value network in the context's precision.
 hipError_t launch_eval(bf_ctx* c, const uint8_t* d_mailbox, size_t n, float* d_scores, float* d_debug, hipStream_t s) {
+    if (!d_debug && use_split(c, n))
+        return bf::launch_eval_t16_split(d_mailbox, bf::kMailboxBytes, false, n, c->d_image16, d_scores, s);
     if (c->precision == BF_PRECISION_BF16)
         return c->tiles32 ? bf::launch_eval_bf16(d_mailbox, n, c->d_image16, d_scores, d_debug, s)
                           : bf::launch_eval_t16(d_mailbox, n, c->d_image16, d_scores, d_debug, s);
@@ -240,7 +255,10 @@ int wire_to_mailbox(Lane* L, const uint8_t* h_pf, size_t n_bytes, const uint64_t
 // Records -> scores (value network) on stream `s`.  `L` = the lane whose mailbox scratch the two-kernel form uses.
 int eval_from_structs(bf_ctx* c, const void* d_structs, size_t stride, size_t n, float* d_scores, hipStream_t s) {
     if (c->precision == BF_PRECISION_BF16 && !c->tiles32 && !c->two_kernels && bf::t16_takes_records(d_structs, stride)) {
-        BF_HIP(bf::launch_eval_t16_structs(d_structs, stride, n, c->d_image16, d_scores, s));
+        if (use_split(c, n))
+            BF_HIP(bf::launch_eval_t16_split(static_cast<const uint8_t*>(d_structs), stride, true, n, c->d_image16, d_scores, s));
+        else
+            BF_HIP(bf::launch_eval_t16_structs(d_structs, stride, n, c->d_image16, d_scores, s));
         return BF_OK;   // no scratch involved
     }
     if (int r = ensure_boards(c, n)) return r;
@@ -307,6 +325,8 @@ extern "C" const char* bf_version(void) { return "batchfirst-hip 0.1 gfx950"; }
 extern "C" int bf_ctx_create(bf_ctx** out, int device, const float* h_weights, size_t n_floats) {
     return bf_ctx_create_ex(out, device, h_weights, n_floats, BF_PRECISION_F32);
 }
+
+extern "C" size_t bf_set_split_boards(size_t n) { return g_split_boards.exchange(n); }
 
 extern "C" int bf_ctx_precision(const bf_ctx* c) { return c ? c->precision : BF_E_ARG; }
 
@@ -761,6 +781,8 @@ int check_policy(const bf_ctx* c, size_t n, const char* who) {
 }
 
 hipError_t launch_policy_features(bf_ctx* c, const uint8_t* d_mailbox, size_t n, float* d_x9, hipStream_t s) {
+    if (use_split(c, n))
+        return bf::launch_policy_features_t16_split(d_mailbox, bf::kMailboxBytes, false, n, c->d_policy_image16, d_x9, s);
     if (c->precision == BF_PRECISION_BF16)
         return c->tiles32 ? bf::launch_policy_features_bf16(d_mailbox, n, c->d_policy_image16, d_x9, s)
                           : bf::launch_policy_features_t16(d_mailbox, n, c->d_policy_image16, d_x9, s);
@@ -771,7 +793,11 @@ hipError_t launch_policy_features(bf_ctx* c, const uint8_t* d_mailbox, size_t n,
 int features_from_structs(bf_ctx* c, const void* d_structs, size_t stride, size_t n, float* d_x9, hipStream_t s) {
     Lane* L = &c->policy;
     if (c->precision == BF_PRECISION_BF16 && !c->tiles32 && !c->two_kernels && bf::t16_takes_records(d_structs, stride)) {
-        BF_HIP(bf::launch_policy_features_t16_structs(d_structs, stride, n, c->d_policy_image16, d_x9, s));
+        if (use_split(c, n))
+            BF_HIP(bf::launch_policy_features_t16_split(static_cast<const uint8_t*>(d_structs), stride, true, n,
+                                                        c->d_policy_image16, d_x9, s));
+        else
+            BF_HIP(bf::launch_policy_features_t16_structs(d_structs, stride, n, c->d_policy_image16, d_x9, s));
         return BF_OK;
     }
     if (int r = ensure_boards(L, n)) return r;

@@ -33,6 +33,7 @@
 #include "bf_device.h"
 #include "bf_kernels.h"
 #include "bf_layout_t16.h"
+#include "t16_common.h"
 
 namespace bf {
 
@@ -40,32 +41,6 @@ namespace t16 {
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int BPB = 4;                   // boards per workgroup = waves per workgroup
-constexpr int WAVES = BPB;
-constexpr int THREADS = 64 * WAVES;
-#ifndef T16_CHUNK
-#define T16_CHUNK 16
-#endif
-#ifndef T16_SLOTS
-#define T16_SLOTS 4
-#endif
-constexpr int CHUNK = T16_CHUNK;         // groups per lockstep chunk of the weight ring
-constexpr int SHARE = CHUNK / WAVES;     // groups each wave fetches per chunk
-constexpr int SLOTS = T16_SLOTS;         // ring slots: one being read, one just read, SLOTS - 2 landed or in flight
-#ifndef T16_LA
-#define T16_LA 3
-#endif
-constexpr int LA = T16_LA;               // groups held in registers ahead of the MFMAs
-constexpr int AHEAD = SLOTS - 2;         // chunks the refill runs ahead of the chunk being read
-constexpr int WALK_CHUNKS = kStreamWalkGroups / CHUNK;
-static_assert(kStreamWalkGroups % CHUNK == 0 && WALK_CHUNKS % SLOTS == 0 && kStreamWalkGroups % (LA + 1) == 0,
-              "every board starts in the same phase of the ring and of the register look-ahead");
-static_assert(SHARE >= 1 && SHARE <= 4 && CHUNK % WAVES == 0 && LA <= CHUNK, "fetch_piece: up to four pieces with immediate offsets");
 
 // Stage 1 reads its B operands from a one-hot image of the board in LDS: grid[row][col][half] of 16-byte
 // entries (8 bf16 planes each), rows -2 .. 9 and columns -7 .. 16 around the board.  Columns: the taps reach 7
@@ -96,142 +71,9 @@ struct Lds {
     __attribute__((aligned(16))) unsigned char next_mailbox[WAVES][256];
 };
 
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// Chunk barrier of the weight ring (see eval_bf16.hip: ring_barrier): this wave's share of the chunk about
-// to be read has landed; (AHEAD - 1) * SHARE younger pieces (+ EXTRA: the mailbox prefetch) may stay in flight.
-template <int EXTRA>
-__device__ __forceinline__ void ring_barrier() {
-    constexpr int N = (AHEAD - 1) * SHARE + EXTRA;
-#ifdef T16_ABL_NOBAR   // timing ablation: waves do not wait for each other (wrong scores)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-#else
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
-#endif
-}
 
-// The next board's mailbox is prefetched after the take of this group (the take that issues the last piece
-// of its chunk), early in stage 2.
-constexpr int kPrefetchGroup = ((kPairBase + 24 + LA + CHUNK - 1) / CHUNK) * CHUNK + SHARE - 1 - LA;
-static_assert((kPrefetchGroup + LA) % CHUNK == SHARE - 1 && kPrefetchGroup >= kPairBase &&
-              kPrefetchGroup + 3 * CHUNK < kStreamGroups, "");
 
-// Lockstep walk over the A-fragment stream through the LDS ring: as in eval_bf16.hip, whose comments give
-// the measurements behind each choice.  INVARIANT (tools/isa_hazards.py checks every build's listing): no
-// VALU write of an SGPR within five wait states in front of the asm LDS-DMA that reads it as its base, and
-// no compiler write of M0 -- the chunk base comes out of scalar adds inside an asm statement.
-struct WStream {
-    const unsigned char* sbase;
-    const unsigned char* sbase0;
-    unsigned voff;
-    unsigned lds_share;
-    f32x4* ring;
-    int rd;
-    int fill;
-    f32x4 pre[LA + 1];
-
-    __device__ __forceinline__ void set_m0(int slot_off) {
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(lds_share + (unsigned)slot_off * 16u) : "memory", "m0");
-    }
-    __device__ __forceinline__ void set_base(int chunk) {
-        const unsigned long long b0 = (unsigned long long)(uintptr_t)sbase0;
-        unsigned lo, hi;
-        asm volatile("s_add_u32 %0, %2, %4\n\ts_addc_u32 %1, %3, 0"
-                     : "=&s"(lo), "=s"(hi)
-                     : "s"((unsigned)b0), "s"((unsigned)(b0 >> 32)), "s"((unsigned)(chunk * CHUNK * 1024))
-                     : "scc");
-        sbase = reinterpret_cast<const unsigned char*>((uintptr_t)(((unsigned long long)hi << 32) | lo));
-    }
-    __device__ __forceinline__ void fetch_piece(int i) {
-#ifdef T16_ABL_NODMA   // timing ablation: no weight DMA (stale ring contents, wrong scores)
-        return;
-#endif
-        if (i == 0) asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase) : "memory");
-        if (i == 1) asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" ::"v"(voff), "s"(sbase) : "memory");
-        if (i == 2) asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" ::"v"(voff), "s"(sbase) : "memory");
-        if (i == 3) asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" ::"v"(voff), "s"(sbase) : "memory");
-    }
-    __device__ __forceinline__ void prefetch_mailbox(const unsigned char* board_bytes, unsigned lds_dst, unsigned voff) {
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2"
-                     ::"s"(lds_dst), "v"(voff), "s"(board_bytes) : "memory", "m0");
-    }
-    __device__ __forceinline__ void prime(const f32x4* stream, f32x4* ring_base, int lane, int wave) {
-        typedef __attribute__((address_space(3))) f32x4* lds_ptr;
-        ring = ring_base + lane;
-        lds_share = (unsigned)(uintptr_t)(lds_ptr)(ring_base + wave * SHARE * 64);
-        sbase0 = sbase = reinterpret_cast<const unsigned char*>(stream + wave * SHARE * 64);
-        voff = (unsigned)lane * 16u;
-#pragma unroll
-        for (int c = 0; c < AHEAD; ++c) {
-            set_m0(c * CHUNK * 64);
-            set_base(c);
-#pragma unroll
-            for (int i = 0; i < SHARE; ++i) fetch_piece(i);
-        }
-        rd = (SLOTS - 1) * CHUNK * 64;
-    }
-    template <int EXTRA>
-    __device__ __forceinline__ void next_chunk() {
-        rd = (rd == (SLOTS - 1) * CHUNK * 64) ? 0 : rd + CHUNK * 64;
-        __builtin_amdgcn_sched_barrier(0);
-        ring_barrier<EXTRA>();
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    __device__ __forceinline__ void aim_refill(int chunk) {
-        fill = rd + (AHEAD + 1) * CHUNK * 64;
-        while (fill >= SLOTS * CHUNK * 64) fill -= SLOTS * CHUNK * 64;
-        set_m0(fill);
-        set_base(chunk % WALK_CHUNKS);
-    }
-    __device__ __forceinline__ void refill_step(int i, int c) {
-        if (i < SHARE) fetch_piece(i);
-        if (i == SHARE) aim_refill(c + 1 + AHEAD);
-    }
-    __device__ __forceinline__ void start() {
-        next_chunk<0>();
-        fill = rd + AHEAD * CHUNK * 64;
-        if (fill >= SLOTS * CHUNK * 64) fill -= SLOTS * CHUNK * 64;
-        set_m0(fill);
-        set_base(AHEAD);
-#pragma unroll
-        for (int i = 0; i < LA; ++i) {
-            refill_step(i, 0);
-            pre[i] = ring[rd + i * 64];
-        }
-    }
-    __device__ __forceinline__ void board_start() { rd = 0; }
-    // g: stream group index, a compile-time constant after unrolling; groups are taken in order.
-    __device__ __forceinline__ bf16x8 take(int g) {
-        const int nx = g + LA, i = nx % CHUNK;
-        const bool extra = nx > kPrefetchGroup + LA && nx <= kPrefetchGroup + LA + AHEAD * CHUNK;
-        if (i == 0) { if (extra) next_chunk<1>(); else next_chunk<0>(); }
-        refill_step(i, nx / CHUNK);
-        pre[nx % (LA + 1)] = ring[rd + i * 64];
-        __builtin_amdgcn_sched_barrier(0);
-        return __builtin_bit_cast(bf16x8, pre[g % (LA + 1)]);
-    }
-};
-
-// bf16(max(a, 0)), bf16(max(b, 0)) packed low / high (one v_cvt_pk_bf16_f32 + one signed 16-bit max)
-__device__ __forceinline__ unsigned pack_relu(float a, float b) {
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const bf16x2 v = __builtin_convertvector(f32x2{a, b}, bf16x2);
-    s16x2 s = __builtin_bit_cast(s16x2, v);
-    s = __builtin_elementwise_max(s, s16x2{0, 0});
-    return __builtin_bit_cast(unsigned, s);
-}
-__device__ __forceinline__ float bf16_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
-__device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xFFFF0000u); }
-
-#ifdef BF_STAMPS
-#define BF_STAMP(i) do { stamps[i] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define BF_STAMP(i) ((void)0)
-#endif
-#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
-
-__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
-__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
 
 // ---- stage 1 as a flat list of units = (conv, step, column tile) that are computed -------------------
 constexpr int kMaxUnits = 176, kMaxJobs = 8;

@@ -99,6 +99,14 @@ int bf_ctx_create_ex(bf_ctx** out, int device, const float* h_weights, size_t n_
 /* The precision a context was created with. */
 int bf_ctx_precision(const bf_ctx* ctx);
 
+/* BF16 contexts run calls of at most this many boards on a second kernel with the same arithmetic (one
+ * board per workgroup instead of one per wave: a third of the latency while the boards are few; the
+ * scores are bit-identical).  Process-wide; returns the previous value; 0 turns the second kernel off.
+ * The environment variable BF_SPLIT_BOARDS sets the start value.  No counterpart in the reference (a
+ * tuning knob of this library: the search's batches at shallow depths are a hundred boards). */
+#define BF_SPLIT_BOARDS_DEFAULT 512u
+size_t bf_set_split_boards(size_t n_boards);
+
 /* Free device memory and streams.  Stands in for closer_fn / sess.close():
  * batch_first/chestimator.py:72. */
 void bf_ctx_destroy(bf_ctx* ctx);

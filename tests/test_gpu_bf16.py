@@ -167,6 +167,62 @@ def test_records_decoded_inside_the_kernel_equal_the_two_kernel_form(weights, go
         two.close()
 
 
+def test_small_calls_on_one_board_per_workgroup_equal_the_dense_kernel(weights, golden):
+    """Calls of up to bf_set_split_boards() boards run k_eval_t16s (one board per workgroup, a column tile per
+    wave); larger ones k_eval_t16 (one board per wave).  Same bits from both, for scores and for the move-scoring
+    network's features, from 4-bit mailboxes (wire format, 806-byte records) and from aligned records; sizes
+    around the number of compute units, odd sizes, one board."""
+    import torch
+    from batch_first_amd import _lib, encoder, ops
+    lib = _lib.load()
+    ctx = ops.DeviceContext(weights, device=0, dtype="bf16")
+    ctx.set_policy(W.make_policy_weights())
+    before = lib.bf_set_split_boards(0)
+    try:
+        assert before == _lib.BF_SPLIT_BOARDS_DEFAULT
+        structs806 = P.test_set(1024, seed=0)
+        r88 = ops.records_to_tensor(P.to_compact(structs806), torch.device("cuda", 0))
+        r806 = ops.records_to_tensor(structs806, torch.device("cuda", 0))
+        sizes = (1, 2, 3, 146, 255, 256, 257, 511, 777, 1024)
+
+        def run(n):
+            idx = (np.arange(n) * 5 + 1) % 1024
+            a88 = r88[torch.from_numpy(idx).cuda()].contiguous()
+            a806 = r806[torch.from_numpy(idx).cuda()].contiguous()
+            sel = structs806[idx]
+            pf, occ = encoder.struct_array_to_ann_inputs(sel, sel[:0], np.ones(n, bool), np.zeros(0, bool), n)
+            out = [torch.ops.batchfirst.eval_structs(ctx.handle, a88).cpu().numpy(),
+                   torch.ops.batchfirst.eval_structs(ctx.handle, a806).cpu().numpy(),
+                   torch.ops.batchfirst.policy_features_structs(ctx.handle, a88).cpu().numpy(),
+                   torch.ops.batchfirst.policy_features_structs(ctx.handle, a806).cpu().numpy()]
+            out.append(torch.ops.batchfirst.eval_wire(ctx.handle, torch.from_numpy(pf).cuda(),
+                                                      torch.from_numpy(occ.view(np.int64)).cuda()).cpu().numpy())
+            return out
+
+        dense = {n: run(n) for n in sizes}
+        assert lib.bf_set_split_boards(1 << 20) == 0
+        for n in sizes:
+            for k, (want, got) in enumerate(zip(dense[n], run(n))):
+                assert got.shape == want.shape
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (n, k)
+        # the two forms of one call agree with each other too (records decoded in the kernel / through mailboxes)
+        assert np.array_equal(dense[257][0].view(np.uint32), dense[257][1].view(np.uint32))
+        # the host entry point (the search's call) at the default switch-over: 146 boards split, 1024 dense
+        lib.bf_set_split_boards(_lib.BF_SPLIT_BOARDS_DEFAULT)
+        compact = P.to_compact(structs806)
+        from batch_first_amd import chestimator
+        pred, _, closer = chestimator.get_inference_functions(weights, dtype="bf16")
+        try:
+            small = pred.eval_structs(compact[:146])
+            whole = pred.eval_structs(compact)
+            assert np.array_equal(small.view(np.uint32), whole[:146].view(np.uint32))
+        finally:
+            closer()
+    finally:
+        lib.bf_set_split_boards(before)
+        ctx.close()
+
+
 @pytest.fixture(scope="module")
 def siblings():
     import os

@@ -27,7 +27,7 @@ def main():
     ctx = bp._handle()
     recs = np.concatenate([S.random_playout_records(FENS[i % 7], 60, 100 + i) for i in range(80)])
     print("records available", len(recs))
-    for n in (1, 16, 64, 256, 1024, 4096):
+    for n in (1, 16, 64, 146, 256, 384, 512, 768, 1024, 4096):
         r = np.ascontiguousarray(recs[:n])
         scores = np.zeros(n, np.float32)
         done = C.c_size_t(0)
