@@ -38,7 +38,8 @@ constexpr int XP_W = 10, POS_BYTES = 64, ROW_BYTES = XP_W * POS_BYTES, PLANE_BYT
 struct LdsS {
     f32x4 wring[SLOTS][CHUNK][64];                       // shared A-fragment ring, 64 KiB
     __attribute__((aligned(16))) unsigned char image[SG_BYTES];
-    __attribute__((aligned(16))) unsigned char plane[2][PLANE_BYTES];   // zero-haloed [10 x 10 positions][32 channels] bf16
+    __attribute__((aligned(16))) unsigned char plane[2][PLANE_BYTES];   // zero-haloed [10 x 10 positions][32 channels] bf16: x4..x9
+    __attribute__((aligned(16))) unsigned char x3plane[4][PLANE_BYTES]; // the four 32-channel chunks of x3, same form
     u32x4 onehot[16][2];
     __attribute__((aligned(16))) float bias3[6 * 32];
     __attribute__((aligned(16))) float bias2[128];
@@ -123,10 +124,13 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_t16s(const uint8_t* __restr
         e.w |= ((j >> 1) == 3u) ? one : 0u;
         lds.onehot[c][hh] = e;
     }
-    for (int i = tid; i < 6 * 32; i += THREADS) lds.bias3[i] = bias[kBiasX4 + i];
-    for (int i = tid; i < 128; i += THREADS) lds.bias2[i] = bias[kBiasX3 + i];
-    for (int i = tid; i < SG_BYTES / 16; i += THREADS) reinterpret_cast<u32x4*>(lds.image)[i] = u32x4{0u, 0u, 0u, 0u};
-    for (int i = tid; i < 2 * PLANE_BYTES / 16; i += THREADS) reinterpret_cast<u32x4*>(lds.plane[0])[i] = u32x4{0u, 0u, 0u, 0u};
+    // every global load first (one latency, not one per table), the LDS zeroing while they are in flight
+    static_assert(6 * 32 <= THREADS && 128 <= THREADS, "one shift per thread");
+    const float shift3 = tid < 6 * 32 ? bias[kBiasX4 + tid] : 0.0f;
+    const float shift2 = tid < 128 ? bias[kBiasX3 + tid] : 0.0f;
+    // the first board's mailbox directly (every later one is prefetched)
+    const unsigned first_dword =
+        reinterpret_cast<const unsigned*>(src + (size_t)blockIdx.x * src_stride)[lane < SRC_DWORDS ? lane : SRC_DWORDS - 1];
     u32x4 hk[16];   // the 8x8 kernels of this wave's sixteen squares
     if (MODE != 2) {
         const f32x4* hwp = headw + (size_t)wave * 16 * 64 + lane;
@@ -135,9 +139,11 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_t16s(const uint8_t* __restr
     }
     const float head_shift = MODE != 2 ? bias[kBiasX10 + (tid & 15)] : 0.0f;
     const float head_logit = MODE != 2 ? bias[kLogitW + (tid & 15)] : 0.0f;
-    if (lane < SRC_DWORDS)   // the first board's mailbox directly (every later one is prefetched)
-        reinterpret_cast<unsigned*>(lds.next_mailbox[wave])[lane] =
-            reinterpret_cast<const unsigned*>(src + (size_t)blockIdx.x * src_stride)[lane];
+    for (int i = tid; i < SG_BYTES / 16; i += THREADS) reinterpret_cast<u32x4*>(lds.image)[i] = u32x4{0u, 0u, 0u, 0u};
+    for (int i = tid; i < 6 * PLANE_BYTES / 16; i += THREADS) reinterpret_cast<u32x4*>(lds.plane[0])[i] = u32x4{0u, 0u, 0u, 0u};
+    if (tid < 6 * 32) lds.bias3[tid] = shift3;
+    if (tid < 128) lds.bias2[tid] = shift2;
+    if (lane < SRC_DWORDS) reinterpret_cast<unsigned*>(lds.next_mailbox[wave])[lane] = first_dword;
     lds_order();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     ws.start();   // (its first chunk barrier also orders the zeroing above before any wave's first use)
@@ -264,47 +270,54 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_t16s(const uint8_t* __restr
 
     BF_STAMP(3);
     // ---- stages 3 and 4: the six 3x3 layers, tiles exchanged through the shared planes ---------------------
-    auto write_tile = [&](int pl, const f32x4& a0, const f32x4& a1) {
+    auto write_tile = [&](unsigned char* pl, const f32x4& a0, const f32x4& a1) {
         u32x4 v;
         v.x = pack_relu(a0[0], a0[1]);
         v.y = pack_relu(a0[2], a0[3]);
         v.z = pack_relu(a1[0], a1[1]);
         v.w = pack_relu(a1[2], a1[3]);
         lds_order();
-        *reinterpret_cast<u32x4*>(lds.plane[pl] + waddr) = v;
+        *reinterpret_cast<u32x4*>(pl + waddr) = v;
         lds_order();
+    };
+    auto load_taps = [&](u32x4 (&dst)[9], const unsigned char* pl) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+            dst[tap] = *reinterpret_cast<const u32x4*>(pl + raddr[tap % 3] + (tap / 3) * ROW_BYTES);
     };
     f32x4 A[2];   // the two output row tiles of this wave's column tile
     f32x4 bs[2];
-    write_tile(0, acc3[0], acc3[1]);
+    u32x4 bq[2][9];
+    // Chunks 0..3 are the four 32-channel input chunks of the 128->32 layer: all of x3 goes into its own four planes
+    // first (last read four barriers ago), so that one barrier covers them and their 72 groups run without a stop.
+#pragma unroll
+    for (int c = 0; c < 4; ++c) write_tile(lds.x3plane[c], acc3[2 * c], acc3[2 * c + 1]);
     bs[0] = *reinterpret_cast<const f32x4*>(&lds.bias3[4 * q]);
     bs[1] = *reinterpret_cast<const f32x4*>(&lds.bias3[16 + 4 * q]);
     lds_barrier();
+    load_taps(bq[0], lds.x3plane[0]);
 #pragma unroll
     for (int c = 0; c < 9; ++c) {
-        // chunk c reads plane c & 1, complete since the barrier in front of it; what is written during the chunk
-        // goes to the other plane, whose readers (chunk c - 1) finished before that barrier
-        u32x4 bq[9];
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-            bq[tap] = *reinterpret_cast<const u32x4*>(lds.plane[c & 1] + raddr[tap % 3] + (tap / 3) * ROW_BYTES);
-        if (c < 3) write_tile((c + 1) & 1, acc3[2 * (c + 1)], acc3[2 * (c + 1) + 1]);
+        if (c < 3) load_taps(bq[(c + 1) & 1], lds.x3plane[c + 1]);
         const bool fresh_layer = c == 0 || c >= 4;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const bf16x8 f0 = ws.take(kConvBase + c * 18 + 2 * tap);
             const bf16x8 f1 = ws.take(kConvBase + c * 18 + 2 * tap + 1);
-            const bf16x8 bn = __builtin_bit_cast(bf16x8, bq[tap]);
+            const bf16x8 bn = __builtin_bit_cast(bf16x8, bq[c & 1][tap]);
             A[0] = MFMA16(f0, bn, (fresh_layer && tap == 0) ? bs[0] : A[0]);
             A[1] = MFMA16(f1, bn, (fresh_layer && tap == 0) ? bs[1] : A[1]);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (c >= 3 && c < 8) {
-            write_tile((c + 1) & 1, A[0], A[1]);
+            // x(c + 1) into plane (c + 1) & 1, whose readers (chunk c - 1) finished before the last barrier; the next
+            // chunk reads it after this one
+            write_tile(lds.plane[(c + 1) & 1], A[0], A[1]);
             bs[0] = *reinterpret_cast<const f32x4*>(&lds.bias3[32 * (c + 1 - 3) + 4 * q]);
             bs[1] = *reinterpret_cast<const f32x4*>(&lds.bias3[32 * (c + 1 - 3) + 16 + 4 * q]);
+            lds_barrier();
+            load_taps(bq[(c + 1) & 1], lds.plane[(c + 1) & 1]);
         }
-        if (c < 8) lds_barrier();
         if (c == 3) BF_STAMP(4);
     }
     BF_STAMP(5);
@@ -321,7 +334,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_t16s(const uint8_t* __restr
             for (int r = 0; r < 4; ++r) o[(16 * tile + 4 * r + q) * 64 + 16 * wave + c16] = fmaxf(A[tile][r], 0.0f);
     } else {
         // ---- stage 5: this wave's sixteen squares of the 8x8 valid conv (every row of the MFMA is this board) ----
-        write_tile(1, A[0], A[1]);   // x9 -> plane 1 (last read in chunk 7); the wave reads back only its own tile
+        write_tile(lds.plane[1], A[0], A[1]);   // x9 -> plane 1 (last read in chunk 7); the wave reads back only its own tile
         u32x4 hb[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
