@@ -26,6 +26,17 @@ def test_library_exports_every_declared_symbol():
     assert lib.bf_version().startswith(b"batchfirst-hip")
 
 
+def test_split_boards_knob_is_process_wide_and_returns_the_previous_value():
+    lib = _lib.load()
+    before = lib.bf_set_split_boards(7)
+    try:
+        assert lib.bf_set_split_boards(0) == 7
+        assert lib.bf_set_split_boards(1 << 20) == 0
+    finally:
+        assert lib.bf_set_split_boards(before) == 1 << 20
+    assert before == _lib.BF_SPLIT_BOARDS_DEFAULT or "BF_SPLIT_BOARDS" in __import__("os").environ
+
+
 def test_pack_rejects_wrong_sizes():
     lib = _lib.load()
     blob = np.zeros(10, np.float32)
