@@ -65,10 +65,12 @@ typedef struct {
     double settle_seconds;      // other children: draw / table / mate checks, move generation (threads)
     double policy_seconds;      // move-scoring: packing (threads) + both evaluator calls
     double value_wait_seconds;  // waiting for the value network after all of the above
-    double update_seconds;      // scores into the tree and the transposition table (one thread)
+    double update_seconds;      // scores into the tree and the transposition table (one thread, beside the next two
+                                // stages): what was left of it when they were done
     double compact_seconds;     // open children kept, re-insertion lists
     double select_seconds;      // open list: insert_and_get_batch
     uint64_t arena_peak;        // most nodes the arena held at once
+    double update_busy_seconds; // the tree update's own time (overlaps policy_seconds and compact_seconds)
 } bfs_stats;
 
 typedef struct bfs_search bfs_search;

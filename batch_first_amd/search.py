@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbatchfirst_search.so")
+# BATCHFIRST_SEARCH_LIB: another build of the search library (A/B timing on one box)
+LIB_PATH = os.environ.get("BATCHFIRST_SEARCH_LIB") or os.path.join(_HERE, "libbatchfirst_search.so")
 
 _c = ctypes
 BOARD_EVAL_FN = _c.CFUNCTYPE(_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_size_t, _c.c_void_p,
@@ -36,7 +37,8 @@ class Stats(_c.Structure):
                 ("seconds", _c.c_double), ("eval_wait_seconds", _c.c_double), ("eval_calls", _c.c_uint64),
                 ("policy_calls", _c.c_uint64), ("expand_seconds", _c.c_double), ("settle_seconds", _c.c_double),
                 ("policy_seconds", _c.c_double), ("value_wait_seconds", _c.c_double), ("update_seconds", _c.c_double),
-                ("compact_seconds", _c.c_double), ("select_seconds", _c.c_double), ("arena_peak", _c.c_uint64)]
+                ("compact_seconds", _c.c_double), ("select_seconds", _c.c_double), ("arena_peak", _c.c_uint64),
+                ("update_busy_seconds", _c.c_double)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

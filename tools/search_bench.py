@@ -42,7 +42,7 @@ def main():
     stages = ["expand_seconds", "settle_seconds", "policy_seconds", "value_wait_seconds", "update_seconds",
               "compact_seconds", "select_seconds"]
     total = {"nodes_out": 0, "boards_evaluated": 0, "moves_scored": 0, "seconds": 0.0, "eval_wait_seconds": 0.0, "iterations": 0,
-             "eval_calls": 0, "policy_calls": 0, **{k: 0.0 for k in stages}}
+             "eval_calls": 0, "policy_calls": 0, "update_busy_seconds": 0.0, **{k: 0.0 for k in stages}}
     threads = 0
     for fen in FENS[:args.fens]:
         s = make()
@@ -71,6 +71,7 @@ def main():
            "host_threads": threads,
            "arena_peak_nodes": max(r["arena_peak"] for r in rows),
            "stage_share": {k[:-8]: total[k] / total["seconds"] for k in stages},
+           "update_busy_share": total["update_busy_seconds"] / total["seconds"],
            **total, "positions": rows}
     print(json.dumps({k: v for k, v in out.items() if k != "positions"}))
     if args.out:
