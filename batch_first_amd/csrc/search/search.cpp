@@ -14,6 +14,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include <sys/mman.h>
@@ -178,7 +179,16 @@ struct bfs_search {
     std::vector<EvalRecord> recs, policy_recs;
     size_t grain_min = 64;   // fewest nodes per piece of a parallel loop (BFS_GRAIN in the environment: tuning)
     // pieces of a parallel loop over n nodes: about four per thread, never smaller than grain_min
-    size_t grain(size_t n) const { return std::max(grain_min, n / (4 * (size_t)pool->threads()) + 1); }
+    // Batches below `wide_batch` nodes run on the pool's narrow group (threads.h): set per batch, the same for
+    // every loop of the batch.  (Which threads run a loop never changes what the search does.)
+    size_t wide_batch = 320;
+    bool wide_now = true;
+    size_t grain(size_t n) const {
+        const size_t active = (size_t)(wide_now ? pool->threads() : pool->narrow_threads());
+        return std::max(grain_min, n / (4 * active) + 1);
+    }
+    template <class F>
+    void par(size_t n, size_t g, F&& f) { pool->for_range(n, g, std::forward<F>(f), wide_now); }
 
     // ---- transposition table (transposition_table.py) ------------------------------------
     TTEntry& entry(u64 h) { return tt[h & tt_mask]; }
@@ -394,7 +404,7 @@ struct bfs_search {
             mv_filt.resize(total);
             mv_per.resize(who.size());
             // stage 1 is started on the records alone; the move lists are packed while the GPU runs it
-            pool->for_range(who.size(), 4 * grain(who.size()), [&](size_t b, size_t e) {
+            par(who.size(), 4 * grain(who.size()), [&](size_t b, size_t e) {
                 for (size_t i = b; i < e; ++i) to_record(who[i]->b, &policy_recs[i]);
             });
             ++stats.policy_calls;
@@ -406,7 +416,7 @@ struct bfs_search {
             for (size_t i = 0; i < total; ++i) scores[i] = total > 1 ? (float)((double)i / (double)(total - 1)) : 0.0f;
         }
         const bool net = cfg.move_start && cfg.move_finish;
-        pool->for_range(who.size(), grain(who.size()), [&](size_t b, size_t e) {
+        par(who.size(), grain(who.size()), [&](size_t b, size_t e) {
             for (size_t i = b; i < e; ++i) {
                 const Node& n = *who[i];
                 tt_index[i] = (int8_t)table_move_index(n);
@@ -442,7 +452,7 @@ struct bfs_search {
         }
         if (who.empty()) return 0;
         const float* scores = move_scores_buf.data();
-        pool->for_range(who.size(), grain(who.size()), [&](size_t b, size_t e) {
+        par(who.size(), grain(who.size()), [&](size_t b, size_t e) {
             for (size_t i = b; i < e; ++i) {
                 Node& n = *who[i];
                 const float* src = scores + move_base[i];
@@ -477,7 +487,7 @@ struct bfs_search {
     void keep_live(const std::vector<int>& cand_ids, size_t from, std::vector<int>* batch) {
         const size_t n = cand_ids.size() - from;
         live.resize(n);
-        pool->for_range(n, grain(n), [&](size_t b, size_t e) {
+        par(n, grain(n), [&](size_t b, size_t e) {
             for (size_t i = b; i < e; ++i) live[i] = should_not_terminate(cand_ids[from + i]) ? 1 : 0;
         });
         for (size_t i = 0; i < n; ++i)
@@ -489,6 +499,7 @@ struct bfs_search {
     // popped is the one that fills it.
     std::vector<int> insert_and_get_batch(const std::vector<int>& ids, const std::vector<float>& scores) {
         stats.nodes_in += ids.size();
+        wide_now = ids.size() >= wide_batch;
         std::vector<int> batch;
         cand.clear();
         if (ids.size() + in_bins < cfg.max_batch_size) {
@@ -501,7 +512,7 @@ struct bfs_search {
             keep_live(cand, 0, &batch);
         } else {
             bin_idx.resize(ids.size());
-            pool->for_range(ids.size(), 4 * grain(ids.size()), [&](size_t b, size_t e) {
+            par(ids.size(), 4 * grain(ids.size()), [&](size_t b, size_t e) {
                 for (size_t i = b; i < e; ++i) bin_idx[i] = (unsigned)bin_of(scores[i]);
             });
             for (size_t i = 0; i < ids.size(); ++i) bins[bin_idx[i]].push_back(ids[i]);
@@ -586,6 +597,7 @@ struct bfs_search {
     int iterate(const std::vector<int>& batch, std::vector<int>* to_insert, std::vector<float>* insert_scores) {
         ++stats.iterations;
         const size_t n = batch.size();
+        wide_now = n >= wide_batch;
         double t0 = now(), t1;
         parent_next_score.resize(n);
         parent_more.resize(n);
@@ -595,7 +607,7 @@ struct bfs_search {
         // the arena afterwards: the arena holds live nodes only and nothing in it ever moves.
         if (fresh.size() < n) fresh.resize(n);
         // depth-zero children first, so that the evaluator gets its boards as early as possible
-        pool->for_range(n, grain(n), [&](size_t b, size_t e) {
+        par(n, grain(n), [&](size_t b, size_t e) {
             for (size_t j = b; j < e; ++j) {
                 if (j + 6 < e) {   // parents lie anywhere in an arena of gigabytes: ask for their lines a few nodes ahead
                     const char* q = reinterpret_cast<const char*>(&nodes[batch[j + 6]]);
@@ -634,7 +646,7 @@ struct bfs_search {
         if (!to_eval.empty()) {
             recs.resize(to_eval.size());
             eval_scores.resize(to_eval.size());
-            pool->for_range(to_eval.size(), 4 * grain(to_eval.size()), [&](size_t b, size_t e) {
+            par(to_eval.size(), 4 * grain(to_eval.size()), [&](size_t b, size_t e) {
                 for (size_t k = b; k < e; ++k) to_record(fresh[to_eval[k]].b, &recs[k]);
             });
             stats.boards_evaluated += to_eval.size();
@@ -644,7 +656,7 @@ struct bfs_search {
         }
         t1 = now(); stats.expand_seconds += t1 - t0; t0 = t1;
         // meanwhile: the other children (draws, table hits, mates, move generation) and their move scores
-        pool->for_range(n, grain(n), [&](size_t b, size_t e) {
+        par(n, grain(n), [&](size_t b, size_t e) {
             for (size_t j = b; j < e; ++j) {
                 if (j + 6 < e) __builtin_prefetch(&tt[fresh[j + 6].b.hash & tt_mask]);
                 Node& c = fresh[j];
@@ -681,7 +693,7 @@ struct bfs_search {
         // another core's cache for the one thread that expands the next batch (depth 5, one thread: 3.3 -> 2.8 M
         // nodes/s; twelve threads: 7.3 -> 7.8 M), so it runs here.
         UpdateCall update_call{this, n};
-        const bool beside = pool->threads() >= kOverlapUpdateThreads;
+        const bool beside = wide_now && pool->threads() >= kOverlapUpdateThreads;
         if (beside) eval_lane->submit(&run_update, &update_call);
         else (void)run_update(&update_call);
         if (!beside) { t1 = now(); stats.update_seconds += t1 - t0; t0 = t1; }
@@ -712,7 +724,7 @@ struct bfs_search {
             throw;
         }
         stats.arena_peak = std::max<uint64_t>(stats.arena_peak, nodes.size());
-        pool->for_range(kept.size(), grain(kept.size()), [&](size_t b, size_t e) {
+        par(kept.size(), grain(kept.size()), [&](size_t b, size_t e) {
             for (size_t i = b; i < e; ++i) {
                 const Node& src = fresh[kept[i]];
                 Node& dst = nodes[base + i];
@@ -772,6 +784,7 @@ struct bfs_search {
         if (!settle(r)) return 0;
         const double t0 = now();
         to_score.assign(1, &nodes[0]);
+        wide_now = false;
         if (int rc = score_begin(to_score)) return rc;
         if (int rc = score_end(to_score)) return rc;
         stats.policy_seconds += now() - t0;
@@ -1072,6 +1085,7 @@ extern "C" int bfs_search_create(bfs_search** out, const bfs_config* cfg) {
     }
     s->cfg.threads = s->pool->threads();
     if (const char* g = std::getenv("BFS_GRAIN")) s->grain_min = std::max<size_t>(1, std::strtoull(g, nullptr, 10));
+    if (const char* w = std::getenv("BFS_WIDE_BATCH")) s->wide_batch = std::strtoull(w, nullptr, 10);   // 0: every batch on all threads
     s->tt_mask = ((u64)1 << cfg->tt_bits) - 1;
     *out = s;
     return 0;
