@@ -222,8 +222,12 @@ void stage_wire(unsigned char* h_in, const StagedWire& w, const uint8_t* h_pf, s
 // needed, and (may_direct) the kernel reads the pinned staging itself: launches and copies are what a small call
 // costs.  Large calls keep the device scan, which beats one host thread from a few thousand boards on.
 // *direct: the staging was not copied to the device; *staged: bytes of staging in use.
+// fuse (nullable): the caller runs a kernel that decodes the wire format itself (eval_t16s.hip): for the small-call
+// branch no mailbox kernel is launched, *fuse receives the staging layout and *fuse_in the device's view of it.
 int wire_to_mailbox(Lane* L, const uint8_t* h_pf, size_t n_bytes, const uint64_t* h_occ, size_t n, unsigned start_nibble,
-                    size_t n_scores, bool may_direct, bool* direct, size_t* staged) {
+                    size_t n_scores, bool may_direct, bool* direct, size_t* staged, StagedWire* fuse = nullptr,
+                    const unsigned char** fuse_in = nullptr) {
+    if (fuse_in) *fuse_in = nullptr;
     const bool host_offsets = n <= kHostOffsetBoards;
     *direct = host_offsets && may_direct && n <= direct_boards() && L->h_in_dev != nullptr;
     if (host_offsets) {
@@ -233,6 +237,12 @@ int wire_to_mailbox(Lane* L, const uint8_t* h_pf, size_t n_bytes, const uint64_t
         stage_wire(L->h_in, w, h_pf, n_bytes, h_occ, n, start_nibble);
         const unsigned char* in = *direct ? L->h_in_dev : L->d_in;
         if (!*direct) BF_HIP(hipMemcpyAsync(L->d_in, L->h_in, w.bytes, hipMemcpyHostToDevice, L->stream));
+        if (fuse && fuse_in) {
+            *fuse = w;
+            *fuse_in = in;
+            *staged = w.bytes;
+            return BF_OK;
+        }
         BF_HIP(bf::launch_mailbox_from_wire_offsets(in + w.off_pf, n_bytes, reinterpret_cast<const uint64_t*>(in), n,
                                                     reinterpret_cast<const unsigned*>(in + w.off_offsets),
                                                     reinterpret_cast<const unsigned*>(in + w.off_bases), L->d_err,
@@ -559,9 +569,19 @@ extern "C" int bf_eval_wire_host(bf_ctx* c, const uint8_t* h_pf, size_t n_bytes,
     if (int r = scratch_acquire(c, c->stream)) return r;
     bool direct = false;
     size_t staged = 0;
-    if (int r = wire_to_mailbox(c, h_pf, n_bytes, h_occ, n, 0, n, c->h_scores_dev != nullptr, &direct, &staged)) return r;
+    StagedWire fw;
+    const unsigned char* fin = nullptr;
+    const bool want_fused = use_split(c, n) && n <= kHostOffsetBoards;
+    if (int r = wire_to_mailbox(c, h_pf, n_bytes, h_occ, n, 0, n, c->h_scores_dev != nullptr, &direct, &staged,
+                                want_fused ? &fw : nullptr, want_fused ? &fin : nullptr))
+        return r;
     direct = direct && c->h_scores_dev != nullptr;
-    BF_HIP(launch_eval(c, c->d_mailbox, n, direct ? c->h_scores_dev : c->d_scores, nullptr, c->stream));
+    if (fin)   // small bf16 call: the evaluating workgroups decode the wire format themselves, one launch
+        BF_HIP(bf::launch_t16_split_wire(fin + fw.off_pf, n_bytes, reinterpret_cast<const uint64_t*>(fin),
+                                         reinterpret_cast<const unsigned*>(fin + fw.off_offsets), n, 0u, c->d_err, c->d_image16,
+                                         direct ? c->h_scores_dev : c->d_scores, false, c->stream));
+    else
+        BF_HIP(launch_eval(c, c->d_mailbox, n, direct ? c->h_scores_dev : c->d_scores, nullptr, c->stream));
     if (int r = scratch_release(c, c->stream)) return r;
     if (!direct) BF_HIP(hipMemcpyAsync(c->h_scores, c->d_scores, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     if (int r = read_err_flag(c, c->stream)) return r;
@@ -913,8 +933,18 @@ extern "C" int bf_policy_start_wire_host(bf_ctx* c, const uint8_t* h_pf, size_t 
         if (int r = scratch_acquire(L, L->stream)) return r;
         bool direct = false;
         size_t staged = 0;
-        if (int r = wire_to_mailbox(L, h_pf, n_bytes, h_occ, n, 0, 1, true, &direct, &staged)) return r;
-        BF_HIP(launch_policy_features(c, L->d_mailbox, n, c->d_x9, L->stream));
+        StagedWire fw;
+        const unsigned char* fin = nullptr;
+        const bool want_fused = use_split(c, n) && n <= kHostOffsetBoards;
+        if (int r = wire_to_mailbox(L, h_pf, n_bytes, h_occ, n, 0, 1, true, &direct, &staged, want_fused ? &fw : nullptr,
+                                    want_fused ? &fin : nullptr))
+            return r;
+        if (fin)
+            BF_HIP(bf::launch_t16_split_wire(fin + fw.off_pf, n_bytes, reinterpret_cast<const uint64_t*>(fin),
+                                             reinterpret_cast<const unsigned*>(fin + fw.off_offsets), n, 0u, L->d_err,
+                                             c->d_policy_image16, c->d_x9, true, L->stream));
+        else
+            BF_HIP(launch_policy_features(c, L->d_mailbox, n, c->d_x9, L->stream));
         if (int r = scratch_release(L, L->stream)) return r;
         c->policy_in_used = (staged + 255) & ~(size_t)255;
         c->policy_no_flags = false;  // the wire decoder reports malformed input through the flag

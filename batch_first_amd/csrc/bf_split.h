@@ -17,4 +17,12 @@ hipError_t launch_eval_t16_split(const uint8_t* d_src, size_t stride, bool recor
 hipError_t launch_policy_features_t16_split(const uint8_t* d_src, size_t stride, bool records, size_t n,
                                             const unsigned char* d_image, float* d_x9, hipStream_t stream);
 
+// The same from the wire format (nibble stream + relevance masks + every board's code offset, as the host entry
+// points stage it): the decode of k_to_mailbox<WireSrc> inside the evaluating workgroup, one launch a call.
+// d_nib 4-byte aligned with 3 readable bytes behind n_bytes; d_offsets less than 4 GiB behind d_occ; d_err the lane's
+// sticky malformed-input flag (stream too short: 1, code 15: 2).  features: x9 instead of scores.
+hipError_t launch_t16_split_wire(const uint8_t* d_nib, size_t n_bytes, const uint64_t* d_occ, const unsigned* d_offsets, size_t n,
+                                 unsigned start_nibble, int* d_err, const unsigned char* d_image, float* d_out, bool features,
+                                 hipStream_t stream);
+
 }  // namespace bf

@@ -45,6 +45,19 @@ struct LdsS {
     __attribute__((aligned(16))) float bias2[128];
     f32x4 hpart[WAVES][64];
     __attribute__((aligned(16))) unsigned char next_mailbox[WAVES][256];   // every wave prefetches its own copy
+    unsigned wire_window[WAVES][16];                     // wire input: the 40 stream bytes that hold the board's codes
+};
+
+// Wire-format input (MODE_ + 8; the host entry points' staging, api.hip: wire_to_mailbox): the board's relevance
+// mask, the number of codes in front of it, and the nibble stream.  The decode is k_to_mailbox<WireSrc>'s
+// (encode.hip; ann_creation_helper.py:55-79), done by the waves that evaluate the board: one launch a call.
+struct WireArgs {
+    const uint64_t* occ;
+    const unsigned* offsets;     // codes of the boards before this one
+    const uint8_t* nib;          // 4-byte aligned, at least 3 readable bytes behind n_bytes
+    unsigned n_bytes;
+    unsigned start_nibble;
+    int* err;                    // sticky malformed-input flag: 1 = stream too short, 2 = code 15
 };
 
 // ---- stage 1: units = (conv, k-step), every one computed ------------------------------------------------
@@ -88,16 +101,19 @@ constexpr bool s1_split_in_grid() {
 }
 static_assert(kS1s.n == kUnits && s1_split_in_grid(), "every tap of every square lands inside the image");
 
-// MODE 0: scores; 2: features (x9 as float32 [board][32][64] into `out`); + 4: node records instead of mailboxes.
+// MODE 0: scores; 2: features (x9 as float32 [board][32][64] into `out`); + 4: node records instead of mailboxes;
+// + 8: wire format (`wire`; src and src_stride unused).
 template <int MODE_>
 __global__ __launch_bounds__(THREADS, 1) void k_eval_t16s(const uint8_t* __restrict__ src, unsigned n_boards,
                                                            const f32x4* __restrict__ wstream,
                                                            const float* __restrict__ bias,
                                                            const f32x4* __restrict__ headw, float* __restrict__ out,
-                                                           unsigned src_stride) {
+                                                           unsigned src_stride, WireArgs wire) {
     constexpr int MODE = MODE_ & 3;
     constexpr bool RECS = (MODE_ & 4) != 0;
-    constexpr int SRC_DWORDS = RECS ? 22 : 8;
+    constexpr bool WIRE = (MODE_ & 8) != 0;
+    static_assert(!(RECS && WIRE), "one input format");
+    constexpr int SRC_DWORDS = WIRE ? 3 : RECS ? 22 : 8;   // wire: mask low, mask high, offset
     __shared__ __attribute__((aligned(16))) LdsS lds;
     const int tid = threadIdx.x;
     const int lane = tid & 63, c16 = lane & 15, q = lane >> 4;
@@ -129,8 +145,17 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_t16s(const uint8_t* __restr
     const float shift3 = tid < 6 * 32 ? bias[kBiasX4 + tid] : 0.0f;
     const float shift2 = tid < 128 ? bias[kBiasX3 + tid] : 0.0f;
     // the first board's mailbox directly (every later one is prefetched)
+    // wire input: what a lane adds to the mask array's base to reach its dword of board b's (mask, offset): 8 b + 4 lane
+    // for the mask's halves, the distance to the offsets + 4 b for every other lane
+    const unsigned wire_lane_off = WIRE ? (lane < 2 ? 4u * (unsigned)lane
+                                                    : (unsigned)(reinterpret_cast<const unsigned char*>(wire.offsets) -
+                                                                 reinterpret_cast<const unsigned char*>(wire.occ)))
+                                        : 0u;
+    const unsigned wire_lane_mul = lane < 2 ? 8u : 4u;
     const unsigned first_dword =
-        reinterpret_cast<const unsigned*>(src + (size_t)blockIdx.x * src_stride)[lane < SRC_DWORDS ? lane : SRC_DWORDS - 1];
+        WIRE ? *reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned char*>(wire.occ) + wire_lane_off +
+                                                  wire_lane_mul * blockIdx.x)
+             : reinterpret_cast<const unsigned*>(src + (size_t)blockIdx.x * src_stride)[lane < SRC_DWORDS ? lane : SRC_DWORDS - 1];
     u32x4 hk[16];   // the 8x8 kernels of this wave's sixteen squares
     if (MODE != 2) {
         const f32x4* hwp = headw + (size_t)wave * 16 * 64 + lane;
@@ -170,9 +195,37 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_t16s(const uint8_t* __restr
     BF_STAMP(0);
 
     // ---- this wave's sixteen squares of the one-hot image ----------------------------------------------
+    if (WIRE) {   // the (at most 33) stream bytes of this board's codes, 4-byte aligned window of 40
+        const unsigned* nm = reinterpret_cast<const unsigned*>(lds.next_mailbox[wave]);
+        const unsigned first_nibble = wire.start_nibble + nm[2];
+        const unsigned wb = (first_nibble >> 1) & ~3u;
+        const unsigned at = wb + 4u * (unsigned)(lane < 10 ? lane : 9);
+        unsigned wv = 0u;
+        if (at < wire.n_bytes) wv = *reinterpret_cast<const unsigned*>(wire.nib + at);
+        if (lane < 10) lds.wire_window[wave][lane] = wv;
+        lds_order();
+    }
     if (lane < 32) {
         unsigned c;
-        if (RECS) {
+        if (WIRE) {
+            const unsigned* nm = reinterpret_cast<const unsigned*>(lds.next_mailbox[wave]);
+            const unsigned long long m = ((unsigned long long)nm[1] << 32) | nm[0];
+            const unsigned first_nibble = wire.start_nibble + nm[2];
+            const unsigned wb = (first_nibble >> 1) & ~3u;
+            c = 15u;
+            if ((m >> wsq) & 1ull) {
+                const unsigned nibble = first_nibble + (unsigned)__popcll(m & ((1ull << wsq) - 1ull));
+                const unsigned byte = nibble >> 1;
+                if (byte >= wire.n_bytes) {   // never read past the stream; the length check reports it
+                    atomicOr(wire.err, 1);
+                } else {
+                    // (byte - wb <= 3 + 32 < 40: a mask has at most 64 bits)
+                    const unsigned v = reinterpret_cast<const unsigned char*>(lds.wire_window[wave])[byte - wb];
+                    c = (nibble & 1u) ? (v & 15u) : (v >> 4);   // even nibble = high half
+                    if (c == 15u) atomicOr(wire.err, 2);
+                }
+            }
+        } else if (RECS) {
             const BoardBits bits = load_board(lds.next_mailbox[wave]);
             c = (unsigned)square_code(bits, relevance_mask(bits), wsq);
         } else {
@@ -245,8 +298,12 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_t16s(const uint8_t* __restr
             const int kind = kPairOrder.kind[p], a = kPairOrder.a[p], bi = kPairOrder.b[p];
             const bf16x8 w = ws.take(g);
             if (g == kPrefetchGroup)
-                ws.prefetch_mailbox(src + (size_t)next_board * src_stride, (unsigned)(uintptr_t)(lds_bytes)lds.next_mailbox[wave],
-                                    (unsigned)(lane < SRC_DWORDS ? lane : SRC_DWORDS - 1) * 4u);
+                if (WIRE)
+                    ws.prefetch_mailbox(reinterpret_cast<const unsigned char*>(wire.occ),
+                                        (unsigned)(uintptr_t)(lds_bytes)lds.next_mailbox[wave], wire_lane_off + wire_lane_mul * next_board);
+                else
+                    ws.prefetch_mailbox(src + (size_t)next_board * src_stride, (unsigned)(uintptr_t)(lds_bytes)lds.next_mailbox[wave],
+                                        (unsigned)(lane < SRC_DWORDS ? lane : SRC_DWORDS - 1) * 4u);
             if (p >= 23 && p < 23 + 2 * kOutTiles && ((p - 23) & 1) == 0)
                 seed[(p - 23) >> 1] = *reinterpret_cast<const f32x4*>(&lds.bias2[16 * ((p - 23) >> 1) + 4 * q]);
             if (kind == 0) {
@@ -392,13 +449,14 @@ hipError_t split_blocks(size_t n, unsigned* blocks) {
 }
 
 template <int MODE_>
-hipError_t launch_split(const uint8_t* d_src, size_t stride, size_t n, const unsigned char* d_image, float* d_out, hipStream_t stream) {
+hipError_t launch_split(const uint8_t* d_src, size_t stride, size_t n, const unsigned char* d_image, float* d_out, hipStream_t stream,
+                        const WireArgs& wire = WireArgs{}) {
     unsigned blocks = 0;
     hipError_t e = split_blocks(n, &blocks);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_eval_t16s<MODE_>, dim3(blocks), dim3(THREADS), 0, stream, d_src, (unsigned)n,
                        reinterpret_cast<const f32x4*>(d_image + kOffStream), reinterpret_cast<const float*>(d_image + kOffBias),
-                       reinterpret_cast<const f32x4*>(d_image + kOffHead), d_out, (unsigned)stride);
+                       reinterpret_cast<const f32x4*>(d_image + kOffHead), d_out, (unsigned)stride, wire);
     return hipGetLastError();
 }
 
@@ -420,6 +478,21 @@ hipError_t launch_policy_features_t16_split(const uint8_t* d_src, size_t stride,
     if (n > 0xFFFFFFFFull || stride > 0xFFFFFFFFull) return hipErrorInvalidValue;
     return records ? t16::launch_split<6>(d_src, stride, n, d_image, d_x9, stream)
                    : t16::launch_split<2>(d_src, stride, n, d_image, d_x9, stream);
+}
+
+// Wire format in (see WireArgs above): d_nib 4-byte aligned with at least 3 readable bytes behind n_bytes, d_offsets
+// within 4 GiB behind d_occ (both hold for the host entry points' staging buffer).  features: x9 instead of scores.
+hipError_t launch_t16_split_wire(const uint8_t* d_nib, size_t n_bytes, const uint64_t* d_occ, const unsigned* d_offsets, size_t n,
+                                 unsigned start_nibble, int* d_err, const unsigned char* d_image, float* d_out, bool features,
+                                 hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const ptrdiff_t gap = reinterpret_cast<const unsigned char*>(d_offsets) - reinterpret_cast<const unsigned char*>(d_occ);
+    if (n > 0x0FFFFFFFull || n_bytes > 0xFFFFFFF0ull || (reinterpret_cast<uintptr_t>(d_nib) & 3u) || gap < 0 ||
+        (unsigned long long)gap + 4ull * n > 0xFFFFFFFFull || !d_err)
+        return hipErrorInvalidValue;
+    const t16::WireArgs wire{d_occ, d_offsets, d_nib, (unsigned)n_bytes, start_nibble, d_err};
+    return features ? t16::launch_split<10>(nullptr, 0, n, d_image, d_out, stream, wire)
+                    : t16::launch_split<8>(nullptr, 0, n, d_image, d_out, stream, wire);
 }
 
 }  // namespace bf

@@ -207,15 +207,46 @@ def test_small_calls_on_one_board_per_workgroup_equal_the_dense_kernel(weights, 
                 assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (n, k)
         # the two forms of one call agree with each other too (records decoded in the kernel / through mailboxes)
         assert np.array_equal(dense[257][0].view(np.uint32), dense[257][1].view(np.uint32))
-        # the host entry point (the search's call) at the default switch-over: 146 boards split, 1024 dense
+        # the host entry points at the default switch-over: 146 boards split, 1024 dense.  The reference's callable
+        # (wire format in, NumPy out) and its move-scoring closure decode the wire format inside the small-call
+        # kernel (one launch): same bits as the mailbox route, malformed input still refused.
         lib.bf_set_split_boards(_lib.BF_SPLIT_BOARDS_DEFAULT)
         compact = P.to_compact(structs806)
         from batch_first_amd import chestimator
-        pred, _, closer = chestimator.get_inference_functions(weights, dtype="bf16")
+        pred, start_moves, closer = chestimator.get_inference_functions(weights, dtype="bf16",
+                                                                        policy_weights=W.make_policy_weights())
         try:
             small = pred.eval_structs(compact[:146])
             whole = pred.eval_structs(compact)
             assert np.array_equal(small.view(np.uint32), whole[:146].view(np.uint32))
+
+            def wire_runs(n):
+                idx = (np.arange(n) * 5 + 1) % 1024
+                sel = structs806[idx]
+                pf, occ = encoder.struct_array_to_ann_inputs(sel, sel[:0], np.ones(n, bool), np.zeros(0, bool), n)
+                per = np.full(n, 3, np.uint8)
+                frm = np.tile(np.array([0, 9, 63], np.uint8), n)
+                flt = np.tile(np.array([0, 17, 72], np.uint8), n)
+                return pf, occ, pred(pf, occ), start_moves(pf, occ)([frm, flt, per])
+
+            for n in (1, 2, 33, 146, 256, 257, 511):
+                lib.bf_set_split_boards(0)
+                _, _, want_s, want_m = wire_runs(n)
+                lib.bf_set_split_boards(_lib.BF_SPLIT_BOARDS_DEFAULT)
+                pf, occ, got_s, got_m = wire_runs(n)
+                assert np.array_equal(got_s.view(np.uint32), want_s.view(np.uint32)), n
+                assert np.array_equal(got_m.view(np.uint32), want_m.view(np.uint32)), n
+                assert np.array_equal(got_s.view(np.uint32), dense[n][0].view(np.uint32)) if n in dense else True
+            bad = pf.copy()
+            bad[len(bad) // 2] = 0xFF                          # code 15 is not a piece code
+            with pytest.raises(ValueError):
+                pred(bad, occ)
+            with pytest.raises(ValueError):
+                pred(pf[:-1], occ)                             # stream shorter than the masks say
+            with pytest.raises(ValueError):
+                start_moves(bad, occ)([np.zeros(0, np.uint8), np.zeros(0, np.uint8), np.zeros(len(occ), np.uint8)])
+            again = pred(pf, occ)                              # the flag does not stick to the next call
+            assert np.array_equal(again.view(np.uint32), got_s.view(np.uint32))
         finally:
             closer()
     finally:
