@@ -527,10 +527,12 @@ struct bfs_search {
                         ++bin;
                         continue;
                     }
-                    cand.push_back(b.back());
-                    b.pop_back();
-                    --in_bins;
-                    --need;
+                    // as many as are needed off the back of the bin, last one first (= one pop at a time)
+                    const size_t k = std::min(need, b.size());
+                    cand.insert(cand.end(), b.rbegin(), b.rbegin() + (std::ptrdiff_t)k);
+                    b.resize(b.size() - k);
+                    in_bins -= k;
+                    need -= k;
                 }
                 if (cand.size() == from) break;
                 keep_live(cand, from, &batch);
