@@ -53,6 +53,10 @@ SIGNATURES = {
     "bf_multi_devices": (_sz, [_vp]),
     "bf_multi_eval_wire_host": (_int, [_vp, _vp, _sz, _vp, _sz, _vp]),
     "bf_multi_eval_structs_host": (_int, [_vp, _vp, _sz, _vp, _sz, _vp, _c.POINTER(_sz)]),
+    "bf_multi_set_min_shard": (_sz, [_vp, _sz]),
+    "bf_multi_policy_start_wire_host": (_int, [_vp, _vp, _sz, _vp, _sz]),
+    "bf_multi_policy_start_structs_host": (_int, [_vp, _vp, _sz, _vp, _sz]),
+    "bf_multi_policy_finish_host": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _vp]),
     "bf_host_split_wire": (_int, [_vp, _sz, _sz, _vp, _vp]),
     "bf_host_encode_wire": (_int, [_vp, _sz, _vp, _sz, _vp, _vp, _c.POINTER(_sz), _c.POINTER(_sz)]),
     "bf_packed_floats": (_sz, []),
@@ -66,8 +70,6 @@ SIGNATURES = {
     "bf_policy_start_wire_host": (_int, [_vp, _vp, _sz, _vp, _sz]),
     "bf_policy_start_structs_host": (_int, [_vp, _vp, _sz, _vp, _sz]),
     "bf_policy_finish_host": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _vp]),
-    "bf_packed_bf16_bytes": (_sz, []),
-    "bf_pack_weights_bf16": (_int, [_vp, _sz, _vp, _sz]),
     "bf_packed_t16_bytes": (_sz, []),
     "bf_pack_weights_t16": (_int, [_vp, _sz, _vp, _sz]),
     # debugging aids, not part of the public header

@@ -72,6 +72,56 @@ def _as_blob(weights):
     return blob
 
 
+def _finish_closure(finish_fn, handle_fn):
+    """The closure start_move_prediction returns (chestimator.py:44-46) over a C finish entry point."""
+
+    def finish(move_info):
+        frm, flt, per = (np.ascontiguousarray(a) for a in move_info)
+        for name, a in (("from_squares", frm), ("move_filters", flt), ("moves_per_board", per)):
+            if a.dtype != np.uint8:   # uint8 placeholders, move_evaluation_ann.py:244-246
+                if a.size and (a.min() < 0 or a.max() > 255):
+                    raise ValueError("%s values must fit uint8" % name)
+        frm, flt, per = frm.astype(np.uint8, copy=False), flt.astype(np.uint8, copy=False), per.astype(np.uint8, copy=False)
+        if frm.shape != flt.shape or frm.ndim != 1 or per.ndim != 1:
+            raise ValueError("from_squares and move_filters must be one-dimensional and equally long")
+        scores = np.empty(frm.size, dtype=np.float32)
+        _lib.check(finish_fn(handle_fn(), frm.ctypes.data, flt.ctypes.data, per.ctypes.data, per.size, frm.size,
+                             scores.ctypes.data))
+        return scores
+
+    return finish
+
+
+# min_shard when none is given: the batch size from which two devices finish a call sooner than one, read off the
+# one-device latency sweep (DESIGN.md section 8, profiles/r2/sweep_r2g.json): a device call costs t(n); cutting 2n
+# boards in two pays when t(2n) > t(n) + the second shard's enqueue (about 10 us).  bf16: t(512) = 40, t(1024) = 47,
+# t(2048) = 75 us -> from 1 024 boards a device; fp32: t(256) = 158, t(512) = 166, t(1024) = 281 us -> from 512.
+# measure_min_shard() repeats the measurement on the box at hand.
+DEFAULT_MIN_SHARD = {"bf16": 1024, "f32": 512}
+
+
+def measure_min_shard(predictor, sizes=(128, 256, 512, 1024, 2048, 4096), reps=9, enqueue_us=10.0):
+    """The smallest shard size s of ``sizes`` with t(2s) > t(s) + enqueue_us on ``predictor``'s device: from 2s boards
+    on, a second device shortens the call.  t = median wall time of ``eval_structs`` on synthetic records (host
+    pointers in, host scores out: what a shard of the multi-device call costs).  Returns (min_shard, {n: us})."""
+    import time
+    from . import positions
+    recs = positions.to_compact(positions.random_structs(2 * max(sizes), seed=7))
+    t = {}
+    for n in sorted(set(list(sizes) + [2 * s for s in sizes])):
+        predictor.eval_structs(recs[:n])
+        samples = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            predictor.eval_structs(recs[:n])
+            samples.append(time.perf_counter() - t0)
+        t[n] = 1e6 * float(np.median(samples))
+    for s in sorted(sizes):
+        if t[2 * s] > t[s] + enqueue_us:
+            return s, t
+    return max(sizes), t
+
+
 class BoardPredictor:
     """Callable evaluator bound to one GPU context."""
 
@@ -139,22 +189,7 @@ class BoardPredictor:
         pf, occ = _wire_arrays(piece_filters, occupied_bbs)
         n = occ.size
         _lib.check(self._lib.bf_policy_start_wire_host(ctx, pf.ctypes.data, pf.size, occ.ctypes.data, n))
-
-        def finish(move_info):
-            frm, flt, per = (np.ascontiguousarray(a) for a in move_info)
-            for name, a in (("from_squares", frm), ("move_filters", flt), ("moves_per_board", per)):
-                if a.dtype != np.uint8:   # uint8 placeholders, move_evaluation_ann.py:244-246
-                    if a.size and (a.min() < 0 or a.max() > 255):
-                        raise ValueError("%s values must fit uint8" % name)
-            frm, flt, per = frm.astype(np.uint8, copy=False), flt.astype(np.uint8, copy=False), per.astype(np.uint8, copy=False)
-            if frm.shape != flt.shape or frm.ndim != 1 or per.ndim != 1:
-                raise ValueError("from_squares and move_filters must be one-dimensional and equally long")
-            scores = np.empty(frm.size, dtype=np.float32)
-            _lib.check(self._lib.bf_policy_finish_host(self._handle(), frm.ctypes.data, flt.ctypes.data, per.ctypes.data,
-                                                       per.size, frm.size, scores.ctypes.data))
-            return scores
-
-        return finish
+        return _finish_closure(self._lib.bf_policy_finish_host, self._handle)
 
     def _handle(self):
         if self._closed:
@@ -181,9 +216,13 @@ class MultiDevicePredictor:
     wire format at sum-of-popcount boundaries (a shard may begin on an odd nibble); all
     shards are enqueued from the calling thread before any is waited for, and one ``float32[N]`` comes
     back in board order.  Scores are bit-identical to a single device's: a board's score does not
-    depend on its place in a batch.  The move-scoring network stays on the first device."""
+    depend on its place in a batch.  The move-scoring network runs on every device the same way
+    (``bf_multi_policy_*``: stage 1 on each device's shard, each device's moves to its second stage).
+    ``min_shard``: a device is used only if every device in use gets that many boards; None = the
+    crossover read off the one-device sweep (DEFAULT_MIN_SHARD), "measure" = measure_min_shard() on
+    the first device at construction."""
 
-    def __init__(self, weights, devices, dtype="f32", min_shard=1024, allow_repeats=False):
+    def __init__(self, weights, devices, dtype="f32", min_shard=None, allow_repeats=False):
         devices = [int(d) for d in devices]
         # allow_repeats: several contexts (streams) on one GPU -- how a one-GPU box runs this path in tests
         if not devices or (len(set(devices)) != len(devices) and not allow_repeats):
@@ -196,7 +235,13 @@ class MultiDevicePredictor:
                 self.parts.append(BoardPredictor(blob, device=d, dtype=dtype))
             arr = (ctypes.c_void_p * len(self.parts))(*[p._ctx for p in self.parts])
             handle = ctypes.c_void_p()
-            _lib.check(self._lib.bf_multi_create(ctypes.byref(handle), arr, len(self.parts), int(min_shard)))
+            self.min_shard_times = None
+            if min_shard is None:
+                min_shard = DEFAULT_MIN_SHARD[self.parts[0].dtype]
+            elif min_shard == "measure":
+                min_shard, self.min_shard_times = measure_min_shard(self.parts[0])
+            self.min_shard = int(min_shard)
+            _lib.check(self._lib.bf_multi_create(ctypes.byref(handle), arr, len(self.parts), self.min_shard))
         except Exception:
             for p in self.parts:
                 p.close()
@@ -210,7 +255,7 @@ class MultiDevicePredictor:
 
     @property
     def has_policy(self):
-        return self.parts[0].has_policy
+        return all(p.has_policy for p in self.parts)
 
     def _multi_handle(self):
         if self._closed:
@@ -218,7 +263,7 @@ class MultiDevicePredictor:
         return self._multi
 
     def _handle(self):
-        """The first device's context (the move-scoring network lives there)."""
+        """The first device's context."""
         self._multi_handle()
         return self.parts[0]._handle()
 
@@ -255,10 +300,15 @@ class MultiDevicePredictor:
         return scores
 
     def set_policy(self, policy_weights):
-        self.parts[0].set_policy(policy_weights)
+        blob = _as_policy_blob(policy_weights)
+        for p in self.parts:
+            p.set_policy(blob)
 
     def start_move_prediction(self, piece_filters, occupied_bbs):
-        return self.parts[0].start_move_prediction(piece_filters, occupied_bbs)
+        m = self._multi_handle()
+        pf, occ = _wire_arrays(piece_filters, occupied_bbs)
+        _lib.check(self._lib.bf_multi_policy_start_wire_host(m, pf.ctypes.data, pf.size, occ.ctypes.data, occ.size))
+        return _finish_closure(self._lib.bf_multi_policy_finish_host, self._multi_handle)
 
     def close(self):
         with self._close_lock:
@@ -277,7 +327,7 @@ class MultiDevicePredictor:
 
 
 def get_inference_functions(weights, session_gpu_memory=.4, device=0, dtype="f32", policy_weights=None, devices=None,
-                            min_shard=1024):
+                            min_shard=None):
     """(board_predictor, start_move_prediction, closer_fn), as batch_first/chestimator.py:51-74.
 
     ``weights`` stands where ``graphdef_filename`` does: a frozen GraphDef file (``.pb`` binary or
@@ -290,7 +340,8 @@ def get_inference_functions(weights, session_gpu_memory=.4, device=0, dtype="f32
     networks.  ``policy_weights``: the move-scoring network's blob (weights.to_policy_blob), file
     or dict.  ``devices``: a list of GPU indices turns ``board_predictor`` into one callable over all
     of them (:class:`MultiDevicePredictor`: contiguous shards, one stream per device, scores gathered
-    to the caller; batches under ``min_shard`` boards per device use fewer devices).
+    to the caller, for both networks; batches under ``min_shard`` boards per device use fewer devices: None =
+    the measured crossover of the one-device sweep, "measure" = measure it now).
     """
     del session_gpu_memory
     if isinstance(weights, (str, os.PathLike)) and _graphdef.is_graphdef_path(weights):

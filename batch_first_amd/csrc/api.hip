@@ -1,8 +1,10 @@
 // C-ABI entry points (include/batchfirst.h): context, device and host evaluation calls.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <atomic>
+#include <functional>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -13,7 +15,6 @@
 #include "bf_encode.h"
 #include "bf_kernels.h"
 #include "bf_layout.h"
-#include "bf_layout_bf16.h"
 #include "bf_layout_t16.h"
 #include "bf_split.h"
 
@@ -60,14 +61,11 @@ struct bf_ctx : Lane {               // the base is the value network's lane
     int device = 0;
     uint8_t* d_static_mailbox = nullptr;  // this device's copy of `scratch` (bf_eval_structs_noalloc)
     int precision = BF_PRECISION_F32;
-    // which bf16 kernel a BF16 context runs: the 16x16x32 one (eval_t16.hip) unless the environment variable
-    // BF_BF16_TILES=32 asked for its 32x32x16 predecessor when the context was created (A/B timing)
-    bool tiles32 = false;
     // BF_T16_TWO_KERNELS=1 at creation: records always go through k_to_mailbox first (A/B and the equality test);
     // otherwise the 16x16x32 kernel decodes 4-byte-aligned records itself (one launch a call)
     bool two_kernels = false;
     float* d_packed = nullptr;            // fp32 image (bf_layout.h) when precision == BF_PRECISION_F32
-    unsigned char* d_image16 = nullptr;   // bf16 image (bf_layout_bf16.h) when precision == BF_PRECISION_BF16
+    unsigned char* d_image16 = nullptr;   // bf16 image (bf_layout_t16.h) when precision == BF_PRECISION_BF16
     // move-scoring network (bf_ctx_set_policy)
     Lane policy;
     float* d_policy_packed = nullptr;          // fp32 image, or ...
@@ -151,7 +149,7 @@ std::atomic<size_t> g_split_boards{[] {
     return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)BF_SPLIT_BOARDS_DEFAULT;
 }()};
 bool use_split(const bf_ctx* c, size_t n) {
-    return c->precision == BF_PRECISION_BF16 && !c->tiles32 && n <= g_split_boards.load(std::memory_order_relaxed);
+    return c->precision == BF_PRECISION_BF16 && n <= g_split_boards.load(std::memory_order_relaxed);
 }
 
 // The value network in the context's precision.
@@ -159,8 +157,7 @@ hipError_t launch_eval(bf_ctx* c, const uint8_t* d_mailbox, size_t n, float* d_s
     if (!d_debug && use_split(c, n))
         return bf::launch_eval_t16_split(d_mailbox, bf::kMailboxBytes, false, n, c->d_image16, d_scores, s);
     if (c->precision == BF_PRECISION_BF16)
-        return c->tiles32 ? bf::launch_eval_bf16(d_mailbox, n, c->d_image16, d_scores, d_debug, s)
-                          : bf::launch_eval_t16(d_mailbox, n, c->d_image16, d_scores, d_debug, s);
+        return bf::launch_eval_t16(d_mailbox, n, c->d_image16, d_scores, d_debug, s);
     return bf::launch_eval_f32(d_mailbox, n, c->d_packed, d_scores, d_debug, s);
 }
 
@@ -264,7 +261,7 @@ int wire_to_mailbox(Lane* L, const uint8_t* h_pf, size_t n_bytes, const uint64_t
 
 // Records -> scores (value network) on stream `s`.  `L` = the lane whose mailbox scratch the two-kernel form uses.
 int eval_from_structs(bf_ctx* c, const void* d_structs, size_t stride, size_t n, float* d_scores, hipStream_t s) {
-    if (c->precision == BF_PRECISION_BF16 && !c->tiles32 && !c->two_kernels && bf::t16_takes_records(d_structs, stride)) {
+    if (c->precision == BF_PRECISION_BF16 && !c->two_kernels && bf::t16_takes_records(d_structs, stride)) {
         if (use_split(c, n))
             BF_HIP(bf::launch_eval_t16_split(static_cast<const uint8_t*>(d_structs), stride, true, n, c->d_image16, d_scores, s));
         else
@@ -278,8 +275,8 @@ int eval_from_structs(bf_ctx* c, const void* d_structs, size_t stride, size_t n,
     return scratch_release(c, s);
 }
 
+// Call with the lane's mutex held: the landing slot h_flag (allocated with the lane, in bf_ctx_create_ex) is the lane's.
 int read_err_flag(Lane* c, hipStream_t s) {
-    if (!c->h_flag) BF_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_flag), 64, hipHostMallocDefault));
     *c->h_flag = 0;
     BF_HIP(hipMemcpyAsync(c->h_flag, c->d_err, sizeof(int), hipMemcpyDeviceToHost, s));
     BF_HIP(hipStreamSynchronize(s));
@@ -367,14 +364,10 @@ extern "C" int bf_ctx_create_ex(bf_ctx** out, int device, const float* h_weights
         return code;
     };
     if (precision == BF_PRECISION_BF16) {
-        static_assert(bf::b16::kImageBytes == bf::t16::kImageBytes && bf::b16::kOffHead == bf::t16::kOffHead, "one allocation size, one logit offset");
-        const char* env = std::getenv("BF_BF16_TILES");
-        c->tiles32 = env && std::strcmp(env, "32") == 0;
         const char* two = std::getenv("BF_T16_TWO_KERNELS");
         c->two_kernels = two && std::strcmp(two, "1") == 0;
-        std::vector<unsigned char> image(bf::b16::kImageBytes);
-        if (c->tiles32) bf::pack_weights_bf16(h_weights, image.data());
-        else bf::pack_weights_t16(h_weights, image.data());
+        std::vector<unsigned char> image(bf::t16::kImageBytes);
+        bf::pack_weights_t16(h_weights, image.data());
         if (hipMalloc(&c->d_image16, image.size()) != hipSuccess)
             return bail(bf::fail(BF_E_HIP, "bf_ctx_create: hipMalloc of the weight image failed"));
         if (hipMemcpy(c->d_image16, image.data(), image.size(), hipMemcpyHostToDevice) != hipSuccess)
@@ -388,7 +381,8 @@ extern "C" int bf_ctx_create_ex(bf_ctx** out, int device, const float* h_weights
             return bail(bf::fail(BF_E_HIP, "bf_ctx_create: weight upload failed"));
     }
     for (Lane* lane : {static_cast<Lane*>(c), &c->policy}) {
-        if (hipMalloc(&lane->d_err, 256) != hipSuccess || hipMemset(lane->d_err, 0, 256) != hipSuccess)
+        if (hipMalloc(&lane->d_err, 256) != hipSuccess || hipMemset(lane->d_err, 0, 256) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void**>(&lane->h_flag), 64, hipHostMallocDefault) != hipSuccess)
             return bail(bf::fail(BF_E_HIP, "bf_ctx_create: flag allocation failed"));
         if (hipStreamCreateWithFlags(&lane->stream, hipStreamNonBlocking) != hipSuccess)
             return bail(bf::fail(BF_E_HIP, "bf_ctx_create: stream creation failed"));
@@ -547,6 +541,7 @@ extern "C" size_t bf_debug_floats_per_board(void) { return bf::kDebugFloatsPerBo
 extern "C" int bf_ctx_check(bf_ctx* c, void* stream) {
     if (!c) return bf::fail(BF_E_ARG, "bf_ctx_check: null context");
     DeviceGuard guard(c->device);
+    std::lock_guard<std::mutex> lock(c->mu);   // the flag's landing slot belongs to the lane
     return read_err_flag(c, (hipStream_t)stream);
 }
 
@@ -633,8 +628,12 @@ extern "C" int bf_eval_structs_host(bf_ctx* c, const void* h_structs, size_t str
 struct bf_multi {
     std::vector<bf_ctx*> ctx;      // one context per device, borrowed (the caller destroys them)
     size_t min_shard = 1024;       // a device is used only if every device in use gets at least this many boards
-    std::mutex mu;                 // one multi-device call at a time (the contexts may still be used directly)
+    std::mutex mu;                 // one multi-device value call at a time (the contexts may still be used directly)
     std::vector<size_t> board_lo, nibble_lo;   // scratch of the call in flight
+    // the move-scoring network over the same devices: the prediction in flight (bf_multi_policy_*)
+    std::mutex policy_mu;
+    std::vector<size_t> policy_lo; // first board of every shard of the started prediction (parts + 1 entries)
+    bool policy_started = false;
 };
 
 extern "C" int bf_multi_create(bf_multi** out, bf_ctx* const* ctxs, size_t n_ctx, size_t min_shard) {
@@ -659,6 +658,15 @@ extern "C" void bf_multi_destroy(bf_multi* m) { delete m; }
 
 extern "C" size_t bf_multi_devices(const bf_multi* m) { return m ? m->ctx.size() : 0; }
 
+extern "C" size_t bf_multi_set_min_shard(bf_multi* m, size_t min_shard) {
+    if (!m) return 0;
+    std::lock_guard<std::mutex> lock(m->mu);
+    std::lock_guard<std::mutex> lock2(m->policy_mu);
+    const size_t prev = m->min_shard;
+    if (min_shard) m->min_shard = min_shard;
+    return prev;
+}
+
 namespace {
 
 size_t parts_for(const bf_multi* m, size_t n) {
@@ -666,6 +674,19 @@ size_t parts_for(const bf_multi* m, size_t n) {
     if (parts < 1) parts = 1;
     return parts < m->ctx.size() ? parts : m->ctx.size();
 }
+
+// The mutexes of the first `parts` contexts' lanes (value lane, or the move-scoring lane), taken in ADDRESS order --
+// two handles built over the same contexts in different orders cannot deadlock -- and released when this goes out
+// of scope, an exception unwinding through the call included.
+struct ShardLocks {
+    std::vector<std::unique_lock<std::mutex>> held;
+    ShardLocks(const bf_multi* m, size_t parts, bool policy_lane) {
+        std::vector<bf_ctx*> order(m->ctx.begin(), m->ctx.begin() + parts);
+        std::sort(order.begin(), order.end(), std::less<bf_ctx*>());
+        held.reserve(parts);
+        for (bf_ctx* c : order) held.emplace_back(policy_lane ? c->policy.mu : c->mu);
+    }
+};
 
 // Enqueue one shard's host-to-device copy, kernels and device-to-host copy on its context's stream.
 // The context's mutex is held by the caller until finish_shard().
@@ -724,11 +745,11 @@ extern "C" int bf_multi_eval_wire_host(bf_multi* m, const uint8_t* h_pf, size_t 
         return bf::fail(BF_E_FORMAT, "bf_multi_eval_wire_host: %zu piece_filters bytes, but the masks select %zu codes (%zu bytes)",
                         n_bytes, total, (total + 1) / 2);
     // all shards are enqueued before any is waited for: the devices run side by side
+    ShardLocks locks(m, parts, false);
     int rc = BF_OK;
     size_t started = 0;
     for (; started < parts && rc == BF_OK; ++started) {
         bf_ctx* c = m->ctx[started];
-        c->mu.lock();
         const size_t s_lo = m->nibble_lo[started], s_hi = m->nibble_lo[started + 1];
         const size_t byte_lo = s_lo >> 1, byte_hi = (s_hi + 1) >> 1;
         rc = start_wire_shard(c, h_pf + byte_lo, byte_hi - byte_lo, (unsigned)(s_lo & 1), h_occ + m->board_lo[started],
@@ -739,7 +760,6 @@ extern "C" int bf_multi_eval_wire_host(bf_multi* m, const uint8_t* h_pf, size_t 
         // a shard that failed to start may have enqueued part of its work: drain it either way
         const int r = finish_shard(c, rc == BF_OK ? m->board_lo[p + 1] - m->board_lo[p] : 0, h_scores + m->board_lo[p], true);
         if (rc == BF_OK) rc = r;
-        c->mu.unlock();
     }
     return rc;
 }
@@ -771,19 +791,18 @@ extern "C" int bf_multi_eval_structs_host(bf_multi* m, const void* h_structs, si
         ++k;
     }
     const size_t parts = parts_for(m, count);
+    ShardLocks locks(m, parts, false);
     int rc = BF_OK;
     size_t started = 0;
     auto lo_of = [&](size_t p) { return p * (count / parts) + (p < count % parts ? p : count % parts); };
     for (; started < parts && rc == BF_OK; ++started) {
         bf_ctx* c = m->ctx[started];
-        c->mu.lock();
         rc = start_struct_shard(c, compact.data() + lo_of(started) * kCompact, lo_of(started + 1) - lo_of(started));
     }
     for (size_t p = 0; p < started; ++p) {
         bf_ctx* c = m->ctx[p];
         const int r = finish_shard(c, rc == BF_OK ? lo_of(p + 1) - lo_of(p) : 0, h_scores + lo_of(p), false);
         if (rc == BF_OK) rc = r;
-        c->mu.unlock();
     }
     if (rc == BF_OK && n_scored) *n_scored = count;
     return rc;
@@ -804,15 +823,14 @@ hipError_t launch_policy_features(bf_ctx* c, const uint8_t* d_mailbox, size_t n,
     if (use_split(c, n))
         return bf::launch_policy_features_t16_split(d_mailbox, bf::kMailboxBytes, false, n, c->d_policy_image16, d_x9, s);
     if (c->precision == BF_PRECISION_BF16)
-        return c->tiles32 ? bf::launch_policy_features_bf16(d_mailbox, n, c->d_policy_image16, d_x9, s)
-                          : bf::launch_policy_features_t16(d_mailbox, n, c->d_policy_image16, d_x9, s);
+        return bf::launch_policy_features_t16(d_mailbox, n, c->d_policy_image16, d_x9, s);
     return bf::launch_policy_features_f32(d_mailbox, n, c->d_policy_packed, d_x9, s);
 }
 
 // Records -> x9 (move-scoring network's tower) on stream `s`, as eval_from_structs.
 int features_from_structs(bf_ctx* c, const void* d_structs, size_t stride, size_t n, float* d_x9, hipStream_t s) {
     Lane* L = &c->policy;
-    if (c->precision == BF_PRECISION_BF16 && !c->tiles32 && !c->two_kernels && bf::t16_takes_records(d_structs, stride)) {
+    if (c->precision == BF_PRECISION_BF16 && !c->two_kernels && bf::t16_takes_records(d_structs, stride)) {
         if (use_split(c, n))
             BF_HIP(bf::launch_policy_features_t16_split(static_cast<const uint8_t*>(d_structs), stride, true, n,
                                                         c->d_policy_image16, d_x9, s));
@@ -828,7 +846,7 @@ int features_from_structs(bf_ctx* c, const void* d_structs, size_t stride, size_
 }
 
 const float* policy_logit_w(const bf_ctx* c) {
-    if (c->precision == BF_PRECISION_BF16) return reinterpret_cast<const float*>(c->d_policy_image16 + bf::b16::kOffHead);
+    if (c->precision == BF_PRECISION_BF16) return reinterpret_cast<const float*>(c->d_policy_image16 + bf::t16::kOffHead);
     return c->d_policy_packed + bf::kOffHead;
 }
 
@@ -853,9 +871,8 @@ extern "C" int bf_ctx_set_policy(bf_ctx* c, const float* h_weights, size_t n_flo
     std::lock_guard<std::mutex> lock(c->policy.mu);
     BF_HIP(hipStreamSynchronize(c->policy.stream));
     if (c->precision == BF_PRECISION_BF16) {
-        std::vector<unsigned char> image(bf::b16::kImageBytes);
-        if (c->tiles32) bf::pack_weights_bf16(h_weights, image.data(), true);
-        else bf::pack_weights_t16(h_weights, image.data(), true);
+        std::vector<unsigned char> image(bf::t16::kImageBytes);
+        bf::pack_weights_t16(h_weights, image.data(), true);
         if (!c->d_policy_image16) BF_HIP(hipMalloc(&c->d_policy_image16, image.size()));
         BF_HIP(hipMemcpy(c->d_policy_image16, image.data(), image.size(), hipMemcpyHostToDevice));
     } else {
@@ -910,20 +927,19 @@ extern "C" int bf_policy_scores(bf_ctx* c, const float* d_x9, size_t n_boards, c
 extern "C" int bf_policy_check(bf_ctx* c, void* stream) {
     if (!c) return bf::fail(BF_E_ARG, "bf_policy_check: null context");
     DeviceGuard guard(c->device);
+    std::lock_guard<std::mutex> lock(c->policy.mu);
     return read_err_flag(&c->policy, (hipStream_t)stream);
 }
 
-extern "C" int bf_policy_start_wire_host(bf_ctx* c, const uint8_t* h_pf, size_t n_bytes, const uint64_t* h_occ, size_t n) {
-    if (int r = check_policy(c, n, "bf_policy_start_wire_host")) return r;
-    if (n && (!h_occ || (!h_pf && n_bytes))) return bf::fail(BF_E_ARG, "bf_policy_start_wire_host: null pointer");
-    size_t total = 0;
-    for (size_t i = 0; i < n; ++i) total += (size_t)__builtin_popcountll(h_occ[i]);
-    if ((total + 1) / 2 != n_bytes)
-        return bf::fail(BF_E_FORMAT, "bf_policy_start_wire_host: %zu piece_filters bytes, but the masks select %zu codes (%zu bytes)",
-                        n_bytes, total, (total + 1) / 2);
-    DeviceGuard guard(c->device);
+namespace {
+
+// ---- the host side of a prediction, with the move-scoring lane's mutex held by the caller (one context's
+// entry points below, and the multi-device ones, which hold every shard's lane) ------------------------------
+
+// Stage 1 from a wire-format shard whose length the caller has checked; start_nibble = 1: the first code is the
+// low nibble of h_pf[0].
+int policy_start_wire_locked(bf_ctx* c, const uint8_t* h_pf, size_t n_bytes, const uint64_t* h_occ, size_t n, unsigned start_nibble) {
     Lane* L = &c->policy;
-    std::lock_guard<std::mutex> lock(L->mu);
     c->policy_started = false;
     if (n) {
         // buffers are reused (and may be regrown): whatever an abandoned prediction left running is drained
@@ -936,12 +952,12 @@ extern "C" int bf_policy_start_wire_host(bf_ctx* c, const uint8_t* h_pf, size_t 
         StagedWire fw;
         const unsigned char* fin = nullptr;
         const bool want_fused = use_split(c, n) && n <= kHostOffsetBoards;
-        if (int r = wire_to_mailbox(L, h_pf, n_bytes, h_occ, n, 0, 1, true, &direct, &staged, want_fused ? &fw : nullptr,
+        if (int r = wire_to_mailbox(L, h_pf, n_bytes, h_occ, n, start_nibble, 1, true, &direct, &staged, want_fused ? &fw : nullptr,
                                     want_fused ? &fin : nullptr))
             return r;
         if (fin)
             BF_HIP(bf::launch_t16_split_wire(fin + fw.off_pf, n_bytes, reinterpret_cast<const uint64_t*>(fin),
-                                             reinterpret_cast<const unsigned*>(fin + fw.off_offsets), n, 0u, L->d_err,
+                                             reinterpret_cast<const unsigned*>(fin + fw.off_offsets), n, start_nibble, L->d_err,
                                              c->d_policy_image16, c->d_x9, true, L->stream));
         else
             BF_HIP(launch_policy_features(c, L->d_mailbox, n, c->d_x9, L->stream));
@@ -954,26 +970,16 @@ extern "C" int bf_policy_start_wire_host(bf_ctx* c, const uint8_t* h_pf, size_t 
     return BF_OK;   // the GPU works on while the caller generates the moves to score
 }
 
-extern "C" int bf_policy_start_structs_host(bf_ctx* c, const void* h_structs, size_t stride, const uint8_t* h_mask, size_t n) {
-    if (int r = check_policy(c, n, "bf_policy_start_structs_host")) return r;
-    if (n && !h_structs) return bf::fail(BF_E_ARG, "bf_policy_start_structs_host: null pointer");
-    if (stride < BF_NODE_EVAL_BYTES) return bf::fail(BF_E_ARG, "bf_policy_start_structs_host: stride %zu < 82", stride);
-    DeviceGuard guard(c->device);
+// Stage 1 from node records: the m records that h_mask (nullable = all) selects among n.
+int policy_start_structs_locked(bf_ctx* c, const void* h_structs, size_t stride, const uint8_t* h_mask, size_t n, size_t m) {
     Lane* L = &c->policy;
-    std::lock_guard<std::mutex> lock(L->mu);
     c->policy_started = false;
     constexpr size_t kCompact = 88;
-    size_t m = 0;
-    if (h_mask) {
-        for (size_t j = 0; j < n; ++j) m += h_mask[j] ? 1 : 0;
-    } else {
-        m = n;
-    }
     if (m) {
         BF_HIP(hipStreamSynchronize(L->stream));
         if (int r = ensure_x9(c, m)) return r;
         // room behind the records for stage 2's move lists (kPolicyMoveRoom moves a board), so that
-        // bf_policy_finish_host can stage them while stage 1 still reads the records
+        // the finish call can stage them while stage 1 still reads the records
         const size_t rec_bytes = (m * kCompact + 255) & ~(size_t)255;
         if (int r = ensure_staging(L, rec_bytes + m * kPolicyMoveRoom * 6 + 64, m * kPolicyMoveRoom)) return r;
         const unsigned char* recs = static_cast<const unsigned char*>(h_structs);
@@ -994,29 +1000,32 @@ extern "C" int bf_policy_start_structs_host(bf_ctx* c, const void* h_structs, si
     return BF_OK;
 }
 
-extern "C" int bf_policy_finish_host(bf_ctx* c, const uint8_t* h_from, const uint8_t* h_filter,
-                                     const uint8_t* h_moves_per_board, size_t n_boards, size_t n_moves, float* h_scores) {
-    if (int r = check_policy(c, n_boards, "bf_policy_finish_host")) return r;
-    DeviceGuard guard(c->device);
+// Stage 2 in two halves, so that several devices' second stages run side by side: enqueue (argument checks,
+// staging of the move lists, the gather kernel, the copy back), then wait (synchronise, flag, scores out).
+struct PolicyPending {
+    size_t n_moves = 0;
+    bool sync_only = false;   // nothing can have raised the flag: synchronise without reading it
+};
+
+int policy_finish_enqueue_locked(bf_ctx* c, const uint8_t* h_from, const uint8_t* h_filter, const uint8_t* h_moves_per_board,
+                                 size_t n_boards, size_t n_moves, PolicyPending* pending, const char* who) {
     Lane* L = &c->policy;
-    std::lock_guard<std::mutex> lock(L->mu);
-    if (!c->policy_started) return bf::fail(BF_E_ARG, "bf_policy_finish_host: no prediction was started");
+    *pending = PolicyPending{};
+    if (!c->policy_started) return bf::fail(BF_E_ARG, "%s: no prediction was started", who);
     c->policy_started = false;
     if (n_boards != c->policy_boards)
-        return bf::fail(BF_E_ARG, "bf_policy_finish_host: %zu boards, but the prediction was started with %zu", n_boards, c->policy_boards);
-    if (n_moves && (!h_from || !h_filter || !h_moves_per_board || !h_scores))
-        return bf::fail(BF_E_ARG, "bf_policy_finish_host: null pointer");
+        return bf::fail(BF_E_ARG, "%s: %zu boards, but the prediction was started with %zu", who, n_boards, c->policy_boards);
+    if (n_moves && (!h_from || !h_filter || !h_moves_per_board))
+        return bf::fail(BF_E_ARG, "%s: null pointer", who);
     size_t total = 0;
     for (size_t b = 0; b < n_boards; ++b) total += h_moves_per_board[b];
     if (total != n_moves)
-        return bf::fail(BF_E_FORMAT, "bf_policy_finish_host: moves_per_board sums to %zu, but %zu moves were given", total, n_moves);
+        return bf::fail(BF_E_FORMAT, "%s: moves_per_board sums to %zu, but %zu moves were given", who, total, n_moves);
     for (size_t m = 0; m < n_moves; ++m)
         if (h_from[m] >= 64 || h_filter[m] >= BF_POLICY_FILTERS)
-            return bf::fail(BF_E_FORMAT, "bf_policy_finish_host: move %zu has from-square %u, filter %u", m, h_from[m], h_filter[m]);
-    if (n_moves == 0) {
-        BF_HIP(hipStreamSynchronize(L->stream));
-        return read_err_flag(L, L->stream);
-    }
+            return bf::fail(BF_E_FORMAT, "%s: move %zu has from-square %u, filter %u", who, m, h_from[m], h_filter[m]);
+    pending->n_moves = n_moves;
+    if (n_moves == 0) return BF_OK;
     // staging: board index u32[n_moves] | from u8[n_moves] | filter u8[n_moves]; np.repeat of the
     // board index as numpy_style_repeat_1d_creator does on the device (ann_creation_helper.py:488-510)
     const size_t from_off = n_moves * sizeof(uint32_t), filter_off = from_off + ((n_moves + 15) & ~(size_t)15);
@@ -1044,11 +1053,193 @@ extern "C" int bf_policy_finish_host(bf_ctx* c, const uint8_t* h_from, const uin
                                     src + filter_off, n_moves, n_boards, L->d_err, direct ? L->h_scores_dev : L->d_scores,
                                     L->stream));
     if (!direct) BF_HIP(hipMemcpyAsync(L->h_scores, L->d_scores, n_moves * sizeof(float), hipMemcpyDeviceToHost, L->stream));
-    if (direct && c->policy_no_flags) {
+    pending->sync_only = direct && c->policy_no_flags;
+    return BF_OK;
+}
+
+int policy_finish_wait_locked(bf_ctx* c, const PolicyPending& pending, float* h_scores) {
+    Lane* L = &c->policy;
+    if (pending.n_moves == 0) {
+        BF_HIP(hipStreamSynchronize(L->stream));
+        return read_err_flag(L, L->stream);
+    }
+    if (pending.sync_only) {
         BF_HIP(hipStreamSynchronize(L->stream));
     } else if (int r = read_err_flag(L, L->stream)) {
         return r;
     }
-    std::memcpy(h_scores, L->h_scores, n_moves * sizeof(float));
+    std::memcpy(h_scores, L->h_scores, pending.n_moves * sizeof(float));
     return BF_OK;
+}
+
+size_t count_selected(const uint8_t* h_mask, size_t n) {
+    if (!h_mask) return n;
+    size_t m = 0;
+    for (size_t j = 0; j < n; ++j) m += h_mask[j] ? 1 : 0;
+    return m;
+}
+
+}  // namespace
+
+extern "C" int bf_policy_start_wire_host(bf_ctx* c, const uint8_t* h_pf, size_t n_bytes, const uint64_t* h_occ, size_t n) {
+    if (int r = check_policy(c, n, "bf_policy_start_wire_host")) return r;
+    if (n && (!h_occ || (!h_pf && n_bytes))) return bf::fail(BF_E_ARG, "bf_policy_start_wire_host: null pointer");
+    size_t total = 0;
+    for (size_t i = 0; i < n; ++i) total += (size_t)__builtin_popcountll(h_occ[i]);
+    if ((total + 1) / 2 != n_bytes)
+        return bf::fail(BF_E_FORMAT, "bf_policy_start_wire_host: %zu piece_filters bytes, but the masks select %zu codes (%zu bytes)",
+                        n_bytes, total, (total + 1) / 2);
+    DeviceGuard guard(c->device);
+    std::lock_guard<std::mutex> lock(c->policy.mu);
+    return policy_start_wire_locked(c, h_pf, n_bytes, h_occ, n, 0);
+}
+
+extern "C" int bf_policy_start_structs_host(bf_ctx* c, const void* h_structs, size_t stride, const uint8_t* h_mask, size_t n) {
+    if (int r = check_policy(c, n, "bf_policy_start_structs_host")) return r;
+    if (n && !h_structs) return bf::fail(BF_E_ARG, "bf_policy_start_structs_host: null pointer");
+    if (stride < BF_NODE_EVAL_BYTES) return bf::fail(BF_E_ARG, "bf_policy_start_structs_host: stride %zu < 82", stride);
+    DeviceGuard guard(c->device);
+    std::lock_guard<std::mutex> lock(c->policy.mu);
+    return policy_start_structs_locked(c, h_structs, stride, h_mask, n, count_selected(h_mask, n));
+}
+
+extern "C" int bf_policy_finish_host(bf_ctx* c, const uint8_t* h_from, const uint8_t* h_filter,
+                                     const uint8_t* h_moves_per_board, size_t n_boards, size_t n_moves, float* h_scores) {
+    if (int r = check_policy(c, n_boards, "bf_policy_finish_host")) return r;
+    if (n_moves && !h_scores) return bf::fail(BF_E_ARG, "bf_policy_finish_host: null pointer");
+    DeviceGuard guard(c->device);
+    std::lock_guard<std::mutex> lock(c->policy.mu);
+    PolicyPending pending;
+    if (int r = policy_finish_enqueue_locked(c, h_from, h_filter, h_moves_per_board, n_boards, n_moves, &pending, "bf_policy_finish_host"))
+        return r;
+    return policy_finish_wait_locked(c, pending, h_scores);
+}
+
+// ---- the move-scoring network over the devices of a bf_multi ------------------------------------------------
+// Boards are cut into contiguous shards exactly as the value calls cut them; every device runs stage 1 on its
+// shard; the finish call hands every device the moves of its boards (moves arrive board by board, so a shard's
+// moves are one contiguous run), enqueues every second stage and only then waits.
+
+namespace {
+
+int multi_policy_check(const bf_multi* m, size_t n, const char* who) {
+    if (!m) return bf::fail(BF_E_ARG, "%s: null handle", who);
+    for (bf_ctx* c : m->ctx)
+        if (int r = check_policy(c, n, who)) return r;
+    return BF_OK;
+}
+
+}  // namespace
+
+extern "C" int bf_multi_policy_start_wire_host(bf_multi* m, const uint8_t* h_pf, size_t n_bytes, const uint64_t* h_occ, size_t n) {
+    if (int r = multi_policy_check(m, n, "bf_multi_policy_start_wire_host")) return r;
+    if (n && (!h_occ || (!h_pf && n_bytes))) return bf::fail(BF_E_ARG, "bf_multi_policy_start_wire_host: null pointer");
+    std::lock_guard<std::mutex> lock(m->policy_mu);
+    m->policy_started = false;
+    const size_t parts = parts_for(m, n);
+    std::vector<size_t> nibble_lo(parts + 1, 0);
+    m->policy_lo.assign(parts + 1, 0);
+    if (n) {
+        if (int r = bf_host_split_wire(h_occ, n, parts, m->policy_lo.data(), nibble_lo.data())) return r;
+    }
+    const size_t total = nibble_lo[parts];
+    if ((total + 1) / 2 != n_bytes)
+        return bf::fail(BF_E_FORMAT, "bf_multi_policy_start_wire_host: %zu piece_filters bytes, but the masks select %zu codes (%zu bytes)",
+                        n_bytes, total, (total + 1) / 2);
+    ShardLocks locks(m, parts, true);
+    for (size_t p = 0; p < parts; ++p) {
+        bf_ctx* c = m->ctx[p];
+        DeviceGuard guard(c->device);
+        if (!guard.ok) return bf::fail(BF_E_HIP, "hipSetDevice(%d) failed", c->device);
+        const size_t s_lo = nibble_lo[p], s_hi = nibble_lo[p + 1];
+        const size_t byte_lo = s_lo >> 1, byte_hi = (s_hi + 1) >> 1;
+        if (int r = policy_start_wire_locked(c, h_pf + byte_lo, byte_hi - byte_lo, h_occ + m->policy_lo[p],
+                                             m->policy_lo[p + 1] - m->policy_lo[p], (unsigned)(s_lo & 1)))
+            return r;
+    }
+    m->policy_started = true;
+    return BF_OK;
+}
+
+extern "C" int bf_multi_policy_start_structs_host(bf_multi* m, const void* h_structs, size_t stride, const uint8_t* h_mask, size_t n) {
+    if (int r = multi_policy_check(m, n, "bf_multi_policy_start_structs_host")) return r;
+    if (n && !h_structs) return bf::fail(BF_E_ARG, "bf_multi_policy_start_structs_host: null pointer");
+    if (stride < BF_NODE_EVAL_BYTES) return bf::fail(BF_E_ARG, "bf_multi_policy_start_structs_host: stride %zu < 82", stride);
+    std::lock_guard<std::mutex> lock(m->policy_mu);
+    m->policy_started = false;
+    const size_t count = count_selected(h_mask, n);
+    const size_t parts = parts_for(m, count);
+    m->policy_lo.assign(parts + 1, 0);
+    for (size_t p = 0; p <= parts; ++p) m->policy_lo[p] = p * (count / parts) + (p < count % parts ? p : count % parts);
+    // first record (selected or not) of every shard: shard p takes the records from there up to shard p + 1's first
+    std::vector<size_t> rec_lo(parts + 1, n);
+    {
+        size_t k = 0, p = 0;
+        for (size_t j = 0; j < n && p < parts; ++j) {
+            if (h_mask && !h_mask[j]) continue;
+            while (p < parts && k == m->policy_lo[p]) rec_lo[p++] = j;
+            ++k;
+        }
+        rec_lo[0] = 0;
+    }
+    ShardLocks locks(m, parts, true);
+    const unsigned char* recs = static_cast<const unsigned char*>(h_structs);
+    for (size_t p = 0; p < parts; ++p) {
+        bf_ctx* c = m->ctx[p];
+        DeviceGuard guard(c->device);
+        if (!guard.ok) return bf::fail(BF_E_HIP, "hipSetDevice(%d) failed", c->device);
+        const size_t j0 = rec_lo[p], j1 = rec_lo[p + 1];
+        if (int r = policy_start_structs_locked(c, recs + j0 * stride, stride, h_mask ? h_mask + j0 : nullptr, j1 - j0,
+                                                m->policy_lo[p + 1] - m->policy_lo[p]))
+            return r;
+    }
+    m->policy_started = true;
+    return BF_OK;
+}
+
+extern "C" int bf_multi_policy_finish_host(bf_multi* m, const uint8_t* h_from, const uint8_t* h_filter,
+                                           const uint8_t* h_moves_per_board, size_t n_boards, size_t n_moves, float* h_scores) {
+    if (int r = multi_policy_check(m, n_boards, "bf_multi_policy_finish_host")) return r;
+    if (n_moves && (!h_from || !h_filter || !h_moves_per_board || !h_scores))
+        return bf::fail(BF_E_ARG, "bf_multi_policy_finish_host: null pointer");
+    std::lock_guard<std::mutex> lock(m->policy_mu);
+    if (!m->policy_started) return bf::fail(BF_E_ARG, "bf_multi_policy_finish_host: no prediction was started");
+    m->policy_started = false;
+    const size_t parts = m->policy_lo.size() - 1;
+    if (n_boards != m->policy_lo[parts])
+        return bf::fail(BF_E_ARG, "bf_multi_policy_finish_host: %zu boards, but the prediction was started with %zu", n_boards,
+                        m->policy_lo[parts]);
+    size_t total = 0;
+    std::vector<size_t> move_lo(parts + 1, 0);
+    for (size_t p = 0, b = 0; p < parts; ++p) {
+        move_lo[p] = total;
+        for (; b < m->policy_lo[p + 1]; ++b) total += h_moves_per_board[b];
+    }
+    move_lo[parts] = total;
+    if (total != n_moves)
+        return bf::fail(BF_E_FORMAT, "bf_multi_policy_finish_host: moves_per_board sums to %zu, but %zu moves were given", total, n_moves);
+    ShardLocks locks(m, parts, true);
+    std::vector<PolicyPending> pending(parts);
+    int rc = BF_OK;
+    size_t started = 0;
+    for (; started < parts && rc == BF_OK; ++started) {
+        bf_ctx* c = m->ctx[started];
+        DeviceGuard guard(c->device);
+        const size_t b0 = m->policy_lo[started], m0 = move_lo[started];
+        rc = policy_finish_enqueue_locked(c, h_from ? h_from + m0 : nullptr, h_filter ? h_filter + m0 : nullptr,
+                                          h_moves_per_board ? h_moves_per_board + b0 : nullptr, m->policy_lo[started + 1] - b0,
+                                          move_lo[started + 1] - m0, &pending[started], "bf_multi_policy_finish_host");
+    }
+    for (size_t p = 0; p < started; ++p) {
+        bf_ctx* c = m->ctx[p];
+        DeviceGuard guard(c->device);
+        if (rc == BF_OK) {
+            rc = policy_finish_wait_locked(c, pending[p], h_scores ? h_scores + move_lo[p] : nullptr);
+        } else {
+            (void)hipStreamSynchronize(c->policy.stream);   // drain what a failed call left enqueued
+        }
+    }
+    // shards that never reached their second stage keep an unfinished prediction: abandon it
+    for (size_t p = 0; p < parts; ++p) m->ctx[p]->policy_started = false;
+    return rc;
 }

@@ -13,8 +13,6 @@ const char* last_error_text();
 // canonical blob -> packed image (bf_layout.h); both sized by the caller
 void pack_weights(const float* blob, float* packed, bool policy = false);
 
-// canonical blob -> bf16 image (bf_layout_bf16.h), b16::kImageBytes bytes
-void pack_weights_bf16(const float* blob, unsigned char* image, bool policy = false);
 
 // canonical blob -> image of the 16x16x32 bf16 kernel (bf_layout_t16.h), t16::kImageBytes bytes
 void pack_weights_t16(const float* blob, unsigned char* image, bool policy = false);

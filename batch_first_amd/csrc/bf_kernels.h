@@ -38,18 +38,13 @@ hipError_t launch_eval_f32(const uint8_t* d_mailbox, size_t n, const float* d_pa
 // float32 [n][32][64]; then one logit per requested move.
 hipError_t launch_policy_features_f32(const uint8_t* d_mailbox, size_t n, const float* d_packed, float* d_x9,
                                       hipStream_t stream);
-hipError_t launch_policy_features_bf16(const uint8_t* d_mailbox, size_t n, const unsigned char* d_image, float* d_x9,
-                                       hipStream_t stream);
 // d_logit_w: the logit kernel as float32 [73][32] (both images keep it at their head offset)
 hipError_t launch_policy_scores(const float* d_x9, const float* d_logit_w, const unsigned* d_board_index,
                                 const uint8_t* d_from, const uint8_t* d_filter, size_t n_moves, size_t n_boards,
                                 int* d_err, float* d_out, hipStream_t stream);
 
-// Same network, bf16 operands with float32 sums; `d_image` is the image bf::pack_weights_bf16 builds.
-hipError_t launch_eval_bf16(const uint8_t* d_mailbox, size_t n, const unsigned char* d_image, float* d_scores,
-                            float* d_debug, hipStream_t stream);
-
-// The bf16 network on v_mfma_f32_16x16x32_bf16 (eval_t16.hip); `d_image` is the image bf::pack_weights_t16 builds.
+// Same network, bf16 operands with float32 sums, on v_mfma_f32_16x16x32_bf16 (eval_t16.hip); `d_image` is the
+// image bf::pack_weights_t16 builds.
 hipError_t launch_eval_t16(const uint8_t* d_mailbox, size_t n, const unsigned char* d_image, float* d_scores,
                            float* d_debug, hipStream_t stream);
 hipError_t launch_policy_features_t16(const uint8_t* d_mailbox, size_t n, const unsigned char* d_image, float* d_x9,

@@ -1,11 +1,12 @@
 // Fragment-ordered weight image of the 16x16x32 bf16 evaluation kernel (eval_t16.hip, pack_t16.cpp).
 //
-// Same arithmetic as bf_layout_bf16.h documents (folded batch-norm, kernels and activations x1..x9
-// rounded to bf16, float32 sums, float32-exact shifts, float32 x10 and logit; CPU model
-// oracle/network.py:forward_bf16_model), re-tiled on v_mfma_f32_16x16x32_bf16: on this part the chip
-// holds a higher clock on that shape than on 32x32x16 at equal cycles per FLOP, and a
-// board's 64 squares become FOUR column tiles, which gives every layer four independent accumulation
-// chains to interleave.
+// Arithmetic of the bf16 variant (BASELINE configs[2]; restated on the CPU by
+// oracle/network.py:forward_bf16_model): batch-norm is folded as in the fp32 path (W' = W * inv in
+// float32), W' is rounded to bf16 (round-to-nearest-even), every activation x1..x9 is rounded to bf16
+// after its ReLU, all sums are float32, the folded batch-norm shifts stay float32-exact, x10 and the
+// logit are float32.  Tiled on v_mfma_f32_16x16x32_bf16: on this part the chip holds a higher clock on
+// that shape than on 32x32x16 at equal cycles per FLOP, and a board's 64 squares become
+// FOUR column tiles, which gives every layer four independent accumulation chains to interleave.
 //
 // Lane maps of v_mfma_f32_16x16x32_bf16 (lane l: c = l & 15, q = l >> 4):
 //   A[row = c][k = 8q + j], B[k = 8q + j][col = c], j = 0..7 (one 16-byte fragment per lane);
@@ -142,7 +143,7 @@ constexpr int kConv59Groups = 5 * 9 * 2;  // 90
 constexpr int kPairBase = kInputGroups;
 constexpr int kConvBase = kPairBase + kPairGroups;                          // 467
 constexpr int kStreamGroups = kConvBase + kConv4Groups + kConv59Groups;     // 629
-constexpr int kStreamWalkGroups = 640;    // walked as a ring: 40 chunks of 16, see bf_layout_bf16.h
+constexpr int kStreamWalkGroups = 640;    // walked as a ring, board after board: padded to 40 chunks of 16, a multiple of the ring's slot count and of the register look-ahead, so that every board starts in the same ring phase
 constexpr int kStreamPadGroups = kStreamWalkGroups - kStreamGroups;         // 11
 static_assert(kStreamPadGroups >= 0, "");
 constexpr size_t kStreamBytes = (size_t)kStreamWalkGroups * kGroupBytes;

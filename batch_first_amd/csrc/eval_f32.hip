@@ -107,7 +107,7 @@ struct WStream {
     // `slot_off` (lane-linear 1 KiB per instruction, exactly the layout the readers expect); no
     // staging registers, no ds_write.  One instruction per group: global address = this lane's pointer +
     // immediate, LDS address = M0 + immediate + lane * 16.
-    // Inline asm on purpose, as in eval_bf16.hip: the compiler models the builtin (global_load_lds) as an
+    // Inline asm on purpose, as in t16_common.h: the compiler models the builtin (global_load_lds) as an
     // access that may touch LDS, and while one is outstanding it turns every LDS wait into lgkmcnt(0): every
     // second group of MFMAs then sat out the LDS read issued right in front of it (1302 such waits in the
     // listing, 5 % of the 1x1 pair's time).  next_chunk() does the vmcnt bookkeeping instead; loads the

@@ -1,6 +1,6 @@
 // The value network as one bf16 kernel on v_mfma_f32_16x16x32_bf16 (BASELINE configs[2]): 4-bit mailboxes
-// in, one score per board out.  Arithmetic and weight image: bf_layout_t16.h.  Successor of eval_bf16.hip
-// (32x32x16 tiles), same structure around the arithmetic: persistent workgroups (one per compute unit),
+// in, one score per board out.  Arithmetic and weight image: bf_layout_t16.h.  Successor of round 1's kernel on
+// 32x32x16 tiles (removed in round 3), same structure around the arithmetic: persistent workgroups (one per compute unit),
 // one wave = one board, the weight stream walked as a ring through LDS by LDS-DMA, every stage a flat,
 // fully unrolled list of MFMA slots with the LDS reads, packs and LDS writes of its neighbours in the gaps.
 //
@@ -171,7 +171,7 @@ static_assert(kS1.n <= kMaxUnits && kS1.ntail <= 64 && s1_jobs_meet_deadlines(),
 __device__ __forceinline__ unsigned s1_pack(int t, int d, const f32x4 (&acc)[2][4][4]) {
     const X1Slot a = x1_slot(2 * d), b = x1_slot(2 * d + 1);
     unsigned p = pack_relu(acc[a.conv & 1][a.tile][t][a.r], acc[b.conv & 1][b.tile][t][b.r]);
-    // pinned where it is scheduled (see eval_bf16.hip: the compiler sinks unpinned packs), and pinned INTO THE
+    // pinned where it is scheduled (the compiler sinks unpinned packs into the next basic block), and pinned INTO THE
     // ACCUMULATOR FILE: x1 is only ever a B operand, which an MFMA reads from an AGPR directly; left to the
     // allocator it stays in the 256 architectural VGPRs, where stage 2's 192 accumulator registers then no
     // longer fit, and the 512->128 accumulators get copied in and out of AGPRs around their MFMAs (730 copy
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_eval_t16(const uint8_t* __restri
     lds_barrier();   // every wave's x9 is in its plane 1 (LDS only: the ring's DMA stays in flight)
     {
         // out[board][co]: activations first (rows = boards, lane l reads board l & 15, chunk l >> 4), kernels
-        // second, read from the AGPRs they were loaded into (inline asm; see eval_bf16.hip)
+        // second, read from the AGPRs they were loaded into (inline asm: the builtin copies them to VGPRs first)
         const unsigned char* xb = lds.board[c16 < BPB ? c16 : 0] + PLANE_BYTES;
         u32x4 hb[SQW], hk[SQW - SQR];
 #pragma unroll

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <chrono>
+#include <climits>
 #include <cmath>
 #include <cstdarg>
 #include <cstddef>
@@ -596,10 +597,24 @@ struct bfs_search {
     // The per-node loops run on the pool; everything that orders nodes (which boards go to the evaluators and
     // in which order, tree and table updates, the open list) stays on the calling thread and walks the batch
     // in index order, so a search does the same thing whatever the number of threads.
+    // The lanes are handed pointers into iterate()'s frame and into the search's per-batch buffers: however the
+    // function is left -- a return, or std::bad_alloc out of any buffer that grows between a submit and its wait --
+    // nothing of the batch may still be running.  (Lane::wait is cheap and idempotent when the lane is idle.)
+    struct LanesJoined {
+        bfs_search* s;
+        ~LanesJoined() {
+            (void)s->eval_lane->wait();
+            (void)s->policy_lane->wait();
+            s->finish_pending = false;
+        }
+    };
+
     int iterate(const std::vector<int>& batch, std::vector<int>* to_insert, std::vector<float>* insert_scores) {
+        LanesJoined joined{this};
         ++stats.iterations;
         const size_t n = batch.size();
         wide_now = n >= wide_batch;
+        if (wide_now) ++stats.wide_iterations;
         double t0 = now(), t1;
         parent_next_score.resize(n);
         parent_more.resize(n);
@@ -679,13 +694,7 @@ struct bfs_search {
         t1 = now(); stats.value_wait_seconds += t1 - t0;
         stats.eval_wait_seconds += t1 - t0;
         t0 = t1;
-        if (eval_rc || score_rc) {
-            if (finish_pending) {   // nothing of this batch may still be running when the call returns
-                (void)policy_lane->wait();
-                finish_pending = false;
-            }
-            return eval_rc ? fail("the value network's evaluation call failed") : score_rc;
-        }
+        if (eval_rc || score_rc) return eval_rc ? fail("the value network's evaluation call failed") : score_rc;
         // The tree update (one thread, in the batch's order) runs on the evaluation lane, which is idle now, while
         // this thread and the pool give the open children their move scores and move them to the arena: the update
         // reads the children's hash / parent / move / value and writes their ANCESTORS and the table; the rest of
@@ -696,14 +705,15 @@ struct bfs_search {
         // nodes/s; twelve threads: 7.3 -> 7.8 M), so it runs here.
         UpdateCall update_call{this, n};
         const bool beside = wide_now && pool->threads() >= kOverlapUpdateThreads;
-        if (beside) eval_lane->submit(&run_update, &update_call);
-        else (void)run_update(&update_call);
+        if (beside) {
+            ++stats.overlapped_updates;
+            eval_lane->submit(&run_update, &update_call);
+        } else {
+            (void)run_update(&update_call);
+        }
         if (!beside) { t1 = now(); stats.update_seconds += t1 - t0; t0 = t1; }
         auto join_update = [&]() { if (beside) (void)eval_lane->wait(); };
-        if (int rc = score_end(to_score)) {
-            join_update();
-            return rc;
-        }
+        if (int rc = score_end(to_score)) return rc;
         t1 = now(); stats.policy_seconds += t1 - t0; t0 = t1;
         // parents with moves left go back to the open list, open children join it
         to_insert->clear();
@@ -715,16 +725,9 @@ struct bfs_search {
             }
         // open children (exactly the ones whose moves were scored, in that order) move to the arena and join the list
         const size_t base = nodes.size();
-        if (base + kept.size() > max_nodes) {
-            join_update();
+        if (base + kept.size() > max_nodes)
             return fail("search arena would exceed its limit of %zu nodes (bfs_config.max_nodes)", max_nodes);
-        }
-        try {
-            nodes.resize(base + kept.size());
-        } catch (...) {
-            join_update();   // nothing of this batch may still be running when the exception leaves
-            throw;
-        }
+        nodes.resize(base + kept.size());   // may throw; LanesJoined joins the update before the exception leaves
         stats.arena_peak = std::max<uint64_t>(stats.arena_peak, nodes.size());
         par(kept.size(), grain(kept.size()), [&](size_t b, size_t e) {
             for (size_t i = b; i < e; ++i) {
@@ -784,6 +787,7 @@ struct bfs_search {
             return 0;
         }
         if (!settle(r)) return 0;
+        LanesJoined joined{this};
         const double t0 = now();
         to_score.assign(1, &nodes[0]);
         wide_now = false;
@@ -1070,6 +1074,10 @@ extern "C" int bfs_search_create(bfs_search** out, const bfs_config* cfg) {
     }
     int threads = cfg->threads;
     if (threads == 0) threads = (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    if (cfg->max_nodes > (size_t)INT_MAX) {   // node ids (parent links, the open list) are ints
+        delete s;
+        return fail("bfs_search_create: max_nodes %zu exceeds the limit of %d", cfg->max_nodes, INT_MAX);
+    }
     if (cfg->max_nodes) s->max_nodes = cfg->max_nodes;
     try {
         s->tt.assign((size_t)1 << cfg->tt_bits, TTEntry());

@@ -44,7 +44,8 @@ typedef struct {
     void* move_user;
     bfs_move_start_fn move_start;    // both null: moves are scored np.linspace(0, 1, total) over the
     bfs_move_finish_fn move_finish;  // batch, the reference's fake policy (code_testing.py:634-640)
-    size_t max_nodes;           // arena limit in nodes (0.8 KB each), checked before the arena grows; 0 = 2^22 (3.5 GB)
+    size_t max_nodes;           // arena limit in nodes (0.8 KB each), checked before the arena grows; 0 = 2^22 (3.5 GB);
+                                // at most INT_MAX (node ids are ints): more is refused by bfs_search_create
     int threads;                // host threads for the per-node loops of a batch (the reference's prange,
                                 // numba_board.py:242-266); 0 = min(8, hardware threads); results do not depend on it
 } bfs_config;
@@ -71,6 +72,9 @@ typedef struct {
     double select_seconds;      // open list: insert_and_get_batch
     uint64_t arena_peak;        // most nodes the arena held at once
     double update_busy_seconds; // the tree update's own time (overlaps policy_seconds and compact_seconds)
+    uint64_t wide_iterations;   // batches of at least `wide_batch` nodes: their loops ran on every pool thread
+    uint64_t overlapped_updates;// of which the tree update ran on the evaluation lane beside the hand-over of the
+                                // move scores and the arena copy (four host threads or more)
 } bfs_stats;
 
 typedef struct bfs_search bfs_search;

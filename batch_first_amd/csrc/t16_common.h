@@ -40,8 +40,14 @@ static_assert(SHARE >= 1 && SHARE <= 4 && CHUNK % WAVES == 0 && LA <= CHUNK, "fe
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// Chunk barrier of the weight ring (see eval_bf16.hip: ring_barrier): this wave's share of the chunk about
-// to be read has landed; (AHEAD - 1) * SHARE younger pieces (+ EXTRA: the mailbox prefetch) may stay in flight.
+// Chunk barrier of the weight ring: this wave's share of the chunk about to be read has landed.  The wave's
+// LDS-DMA queue holds, oldest first, its shares of that chunk and of the AHEAD - 1 chunks after it; vector-memory
+// operations retire in order, so leaving (AHEAD - 1) * SHARE of them outstanding is enough (younger ordinary
+// loads only make the wait stricter).  No LDS wait: the slot refilled after the barrier is that of the chunk
+// BEFORE the one just finished, whose reads were issued more than CHUNK groups ago and have returned (LDS
+// returns a wave's reads in order, and every group waits for its own fragment, issued LA groups earlier).
+// EXTRA = 1 for the AHEAD barriers after the next board's mailbox prefetch (one more LDS-DMA, issued right
+// after a chunk's pieces): it is younger than the pieces those barriers need and may stay in flight.
 template <int EXTRA>
 __device__ __forceinline__ void ring_barrier() {
     constexpr int N = (AHEAD - 1) * SHARE + EXTRA;
@@ -58,10 +64,24 @@ constexpr int kPrefetchGroup = ((kPairBase + 24 + LA + CHUNK - 1) / CHUNK) * CHU
 static_assert((kPrefetchGroup + LA) % CHUNK == SHARE - 1 && kPrefetchGroup >= kPairBase &&
               kPrefetchGroup + 3 * CHUNK < kStreamGroups, "");
 
-// Lockstep walk over the A-fragment stream through the LDS ring: as in eval_bf16.hip, whose comments give
-// the measurements behind each choice.  INVARIANT (tools/isa_hazards.py checks every build's listing): no
-// VALU write of an SGPR within five wait states in front of the asm LDS-DMA that reads it as its base, and
-// no compiler write of M0 -- the chunk base comes out of scalar adds inside an asm statement.
+// Lockstep walk over the A-fragment stream through the LDS ring (DESIGN.md 3.2 gives the measurements behind
+// each choice).  LDS-DMA: one 1-KiB piece of this wave's share straight from L2 into a ring slot, lane-linear,
+// ONE instruction per piece: global address = scalar base + lane * 16 + immediate, LDS address = M0 + immediate
+// + lane * 16 (the immediate applies to both sides), so M0 and the scalar base are set once per chunk and the
+// SHARE pieces differ in their immediates only (with one wave per SIMD every scalar ALU instruction in an MFMA
+// gap costs 8 cycles of issue, the piece itself next to nothing: tools/issue_rate.hip, tools/dma_issue_cost.hip).
+// Inline asm on purpose: the compiler models global_load_lds as a FLAT access that may touch LDS, and while one
+// is outstanding it turns every LDS wait into lgkmcnt(0), which stalls each group of MFMAs on the read just
+// issued; ring_barrier() does the vmcnt bookkeeping instead.
+// The scalar base of a chunk's pieces comes out of two scalar adds inside an asm statement, where the chunk's
+// refill starts: left to itself the compiler keeps all 40 chunk bases of a board in SGPRs and spills them to
+// VGPR lanes, and round-1 builds of that form faulted on the GPU (memory aperture violation,
+// profiles/r2/aperture_violation_isa.txt): a spilled base came back by v_readlane_b32 directly in front of the
+// asm global_load_lds_dwordx4 that reads it; a vector-memory instruction that reads an SGPR written by a VALU
+// instruction needs five wait states, which hipcc pads for its own loads but not for an asm block.
+// INVARIANT (tools/isa_hazards.py checks every build's listing; a build that breaks it yields no object file):
+// no VALU write of an SGPR within five wait states in front of the asm LDS-DMA that reads it as its base, and
+// no compiler write of M0.
 struct WStream {
     const unsigned char* sbase;
     const unsigned char* sbase0;

@@ -38,7 +38,8 @@ class Stats(_c.Structure):
                 ("policy_calls", _c.c_uint64), ("expand_seconds", _c.c_double), ("settle_seconds", _c.c_double),
                 ("policy_seconds", _c.c_double), ("value_wait_seconds", _c.c_double), ("update_seconds", _c.c_double),
                 ("compact_seconds", _c.c_double), ("select_seconds", _c.c_double), ("arena_peak", _c.c_uint64),
-                ("update_busy_seconds", _c.c_double)]
+                ("update_busy_seconds", _c.c_double), ("wide_iterations", _c.c_uint64),
+                ("overlapped_updates", _c.c_uint64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -219,8 +220,13 @@ class Search:
         else:
             args = dict(board_eval=_c.cast(lib.bf_eval_structs_host, _c.c_void_p).value, eval_user=ctx)
         if use_policy and predictor.has_policy:
-            args.update(move_start=_c.cast(lib.bf_policy_start_structs_host, _c.c_void_p).value,
-                        move_finish=_c.cast(lib.bf_policy_finish_host, _c.c_void_p).value, move_user=ctx)
+            if hasattr(predictor, "_multi_handle"):
+                args.update(move_start=_c.cast(lib.bf_multi_policy_start_structs_host, _c.c_void_p).value,
+                            move_finish=_c.cast(lib.bf_multi_policy_finish_host, _c.c_void_p).value,
+                            move_user=predictor._multi_handle())
+            else:
+                args.update(move_start=_c.cast(lib.bf_policy_start_structs_host, _c.c_void_p).value,
+                            move_finish=_c.cast(lib.bf_policy_finish_host, _c.c_void_p).value, move_user=ctx)
         args.update(kw)
         s = cls(**args)
         s._keep.append(predictor)

@@ -33,8 +33,7 @@ PEAK_HBM_GBS = 8000.0
 # tools/pmc_summary.py).  Counters cannot be read from inside this process, so the figure is the
 # committed measurement of the same kernel and batch, not a live one.
 TRAFFIC_PROFILES = {"f32": "profiles/r2/pmc_k_eval_f32_r2f.json", "bf16": "profiles/r2/pmc_k_eval_t16_r2f.json"}
-# the bf16 kernel the library launches: the 16x16x32 one unless BF_BF16_TILES=32 selects its predecessor
-BF16_KERNEL = "k_eval_bf16" if os.environ.get("BF_BF16_TILES") == "32" else "k_eval_t16"
+BF16_KERNEL = "k_eval_t16"
 
 
 def profiled_traffic(dtype):

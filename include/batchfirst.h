@@ -73,9 +73,7 @@ enum {
  *                      within 1e-4 relative of the float32 CPU evaluation of the reference's graph.
  *   BF_PRECISION_BF16  batch-norm-folded weights and every activation x1..x9 rounded to bf16
  *                      (round-to-nearest-even), float32 sums, shifts, x10 and logit
- *                      (v_mfma_f32_16x16x32_bf16; the round-1 kernel on v_mfma_f32_32x32x16_bf16, same
- *                      arithmetic, is selected by the environment variable BF_BF16_TILES=32 when the
- *                      context is created).  No reference counterpart: the reference runs
+ *                      (v_mfma_f32_16x16x32_bf16).  No reference counterpart: the reference runs
  *                      TensorRT/TensorFlow in FP32 only (ann_creation_helper.py:182-187). */
 enum { BF_PRECISION_F32 = 0, BF_PRECISION_BF16 = 1 };
 
@@ -206,6 +204,9 @@ int bf_multi_eval_wire_host(bf_multi* m, const uint8_t* h_piece_filters, size_t 
                             const uint64_t* h_occupied_bbs, size_t n, float* h_scores);
 int bf_multi_eval_structs_host(bf_multi* m, const void* h_structs, size_t stride, const uint8_t* h_mask,
                                size_t n, float* h_scores, size_t* n_scored);
+/* Change min_shard (0 = leave it); returns the previous value.  batch_first_amd/chestimator.py measures the
+ * crossover on the box it runs on (the batch size from which two devices finish a call sooner than one). */
+size_t bf_multi_set_min_shard(bf_multi* m, size_t min_shard);
 
 /* ---- the move-scoring ("policy") network ------------------------------------------------
  *
@@ -262,6 +263,19 @@ int bf_policy_start_structs_host(bf_ctx* ctx, const void* h_structs, size_t stri
 int bf_policy_finish_host(bf_ctx* ctx, const uint8_t* h_from_square, const uint8_t* h_move_filter,
                           const uint8_t* h_moves_per_board, size_t n_boards, size_t n_moves, float* h_scores);
 
+/* The same three calls over the devices of a bf_multi handle, every context of which must have been given a
+ * move-scoring network by bf_ctx_set_policy: the
+ * boards are cut into contiguous shards as the value calls cut them, every device runs stage 1 on its shard,
+ * and the finish call hands each device the moves of its boards (moves arrive board by board, so a shard's
+ * moves are one run), enqueues every second stage and only then waits.  One prediction per handle is in
+ * flight.  Signatures match the single-context calls with the handle in place of the context, so the search
+ * driver takes either.  No counterpart in the reference (one '/GPU:0' session, chestimator.py:33). */
+int bf_multi_policy_start_wire_host(bf_multi* m, const uint8_t* h_piece_filters, size_t n_bytes,
+                                    const uint64_t* h_occupied_bbs, size_t n);
+int bf_multi_policy_start_structs_host(bf_multi* m, const void* h_structs, size_t stride, const uint8_t* h_mask, size_t n);
+int bf_multi_policy_finish_host(bf_multi* m, const uint8_t* h_from_square, const uint8_t* h_move_filter,
+                                const uint8_t* h_moves_per_board, size_t n_boards, size_t n_moves, float* h_scores);
+
 /* ---- host-only helpers (no GPU needed) ----------------------------------------------- */
 
 /* The host encoder itself, for callers that still want the wire format:
@@ -284,11 +298,7 @@ int bf_pack_weights(const float* h_weights, size_t n_floats, float* h_packed, si
 
 int bf_pack_policy_weights(const float* h_weights, size_t n_floats, float* h_packed, size_t n_packed);
 
-/* The same for the bf16 image (bytes). */
-size_t bf_packed_bf16_bytes(void);
-int bf_pack_weights_bf16(const float* h_weights, size_t n_floats, void* h_image, size_t n_bytes);
-
-/* The same for the image of the 16x16x32 bf16 kernel (batch_first_amd/csrc/bf_layout_t16.h), which is
+/* The same for the image of the bf16 kernels (bytes; batch_first_amd/csrc/bf_layout_t16.h), which is
  * what a BF_PRECISION_BF16 context uploads; checked on a CPU by tests/kernel_sim_t16.py. */
 size_t bf_packed_t16_bytes(void);
 int bf_pack_weights_t16(const float* h_weights, size_t n_floats, void* h_image, size_t n_bytes);

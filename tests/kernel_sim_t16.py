@@ -9,7 +9,18 @@ Test infrastructure only.  Constants restate batch_first_amd/csrc/bf_layout_t16.
 import numpy as np
 
 from kernel_sim import bf16_bits_to_float
-from kernel_sim_bf16 import bf16r, pack_relu
+
+
+def bf16r(x):
+    """float -> nearest bf16 (ties to even) as float64."""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32)
+    u = (u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)
+    return u.view(np.float32).astype(np.float64)
+
+
+def pack_relu(a):
+    """ReLU then bf16 of accumulator values kept in float32 on the GPU."""
+    return bf16r(np.maximum(a, 0).astype(np.float32))
 
 INPUT_CONVS = [(3, 1, 1, 64, 0), (3, 2, 2, 32, 64), (3, 3, 3, 20, 96), (3, 4, 4, 20, 116), (3, 5, 5, 18, 136),
                (3, 6, 6, 18, 154), (3, 7, 7, 16, 172), (2, 2, 4, 24, 188), (2, 4, 2, 24, 212)]

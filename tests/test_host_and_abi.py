@@ -113,26 +113,6 @@ def test_no_gpu_means_loud_failure():
         chestimator.get_inference_functions(W.to_blob(W.make_weights()))
 
 
-def test_bf16_image_drives_kernel_model_to_bf16_oracle(golden):
-    """Same for the bf16 image (tests/kernel_sim_bf16.py vs oracle.network.forward_bf16_model)."""
-    import kernel_sim_bf16
-    lib = _lib.load()
-    w = W.make_weights(seed=1234, bn="perturbed")
-    blob = W.to_blob(w)
-    image = np.zeros(lib.bf_packed_bf16_bytes(), np.uint8)
-    _lib.check(lib.bf_pack_weights_bf16(blob.ctypes.data, blob.size, image.ctypes.data, image.size))
-    idx = [1, 500]
-    scores, inters = kernel_sim_bf16.eval_boards(image, golden["mailbox"][idx])
-    planes = E.decode_planes_fast(golden["piece_filters"], golden["occupied_bbs"])[idx]
-    ref, ri = N.forward_bf16_model(planes, w, return_intermediates=True, double=True)
-    for name in ("x1", "x3", "x4", "x9"):
-        got = np.stack([i[name] for i in inters])
-        assert np.array_equal(got, ri[name].reshape(got.shape)), name   # bf16 values: exact
-    assert np.max(np.abs(scores - ref)) <= 1e-6
-    rc = lib.bf_pack_weights_bf16(blob.ctypes.data, blob.size, image.ctypes.data, image.size - 1)
-    assert rc == _lib.BF_E_ARG
-
-
 def test_t16_image_drives_kernel_model_to_bf16_oracle(golden):
     """The image of the 16x16x32 bf16 kernel (bf_pack_weights_t16) walked lane by lane as eval_t16.hip walks
     it (tests/kernel_sim_t16.py): every bf16 activation equals oracle.network.forward_bf16_model's, i.e. the

@@ -255,3 +255,80 @@ def test_policy_orders_the_legal_moves_of_real_parents(pweights, dtype):
     print("policy ordering: %d best moves and %d pairs kept above the gap; %d of %d pairs differ below it"
           % (rep["top_checked"], rep["pairs_checked"], rep["flipped_below_gap"], rep["pairs"]))
     assert rep["groups"] == 128 and rep["pairs_checked"] > (40000 if dtype == "f32" else 1000)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_policy_over_several_devices_equals_one_device(pweights, pgolden, golden, dtype):
+    """MultiDevicePredictor.start_move_prediction: stage 1 of the move-scoring network on every device's shard
+    of the boards, each device's moves to its own second stage (bf_multi_policy_*).  On a one-GPU box three
+    contexts on device 0 stand behind the handle, so the board split (odd-nibble shard starts included), the
+    split of the move lists at board boundaries and the gather run either way.  Scores are bit-equal to one
+    device's for every batch size; the native search takes the handle through the same function pointers."""
+    import torch
+    from batch_first_amd import chestimator, search
+    w = W.to_blob(W.make_weights(seed=1234, bn="perturbed"))
+    single, start1, close1 = chestimator.get_inference_functions(w, dtype=dtype, policy_weights=pweights)
+    count = torch.cuda.device_count()
+    devices = list(range(count)) if count > 1 else [0, 0, 0]
+    multi = chestimator.MultiDevicePredictor(w, devices, dtype=dtype, min_shard=32, allow_repeats=count == 1)
+    try:
+        assert not multi.has_policy
+        multi.set_policy(pweights)
+        assert multi.has_policy
+        structs = np.frombuffer(golden["records"].tobytes(), dtype=P.COMPACT_DTYPE)[:256]
+        per = pgolden["moves_per_board"].astype(np.int64)
+        ends = np.concatenate([[0], np.cumsum(per)])
+        for n in (256, 255, 100, 97, 33, 1):
+            nib, occ = E.struct_array_to_ann_inputs(structs[:n])
+            info = [pgolden["from_squares"][:ends[n]], pgolden["move_filters"][:ends[n]], pgolden["moves_per_board"][:n]]
+            want = start1(nib, occ)(info)
+            got = multi.start_move_prediction(nib, occ)(info)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), n
+        # no moves for some shard, and errors
+        nib, occ = E.struct_array_to_ann_inputs(structs[:96])
+        per0 = pgolden["moves_per_board"][:96].copy()
+        per0[32:64] = 0
+        keep = np.concatenate([np.arange(ends[0], ends[32]), np.arange(ends[64], ends[96])])
+        info0 = [pgolden["from_squares"][keep], pgolden["move_filters"][keep], per0]
+        assert np.array_equal(multi.start_move_prediction(nib, occ)(info0), start1(nib, occ)(info0))
+        with pytest.raises(ValueError):
+            multi.start_move_prediction(nib[:-1], occ)
+        f = multi.start_move_prediction(nib, occ)
+        with pytest.raises(ValueError):
+            f([info0[0], info0[1], per0[:-1]])
+        with pytest.raises(ValueError):   # the failed call abandoned the prediction
+            f(info0)
+        # the search: same value, move and counters with the move-scoring network on one device or on all
+        fen = "r3k2r/p1ppqpb1/bn2pnp1/3PN3/1p2P3/2N2Q1p/PPPBBPPP/R3K2R w KQkq - 0 1"
+        multi_small = chestimator.MultiDevicePredictor(w, devices, dtype=dtype, min_shard=8, allow_repeats=count == 1)
+        try:
+            multi_small.set_policy(pweights)
+            results = []
+            for pred in (single, multi_small):
+                s = search.Search.on_gpu(pred, use_policy=True, max_batch_size=512, threads=2)
+                value, move = s.mtd_f(fen, 3)
+                st = s.stats()
+                results.append((value, tuple(move), st["iterations"], st["nodes_out"], st["boards_evaluated"], st["moves_scored"]))
+                s.close()
+            assert results[0] == results[1]
+        finally:
+            multi_small.close()
+    finally:
+        multi.close()
+        close1()
+
+
+@pytest.mark.gpu
+def test_measured_min_shard_is_a_crossover():
+    """measure_min_shard: t(2s) > t(s) + the second shard's enqueue at the returned s, and not at the sizes below."""
+    from batch_first_amd import chestimator
+    w = W.to_blob(W.make_weights(seed=1234, bn="perturbed"))
+    bp = chestimator.BoardPredictor(w, dtype="bf16")
+    try:
+        s, t = chestimator.measure_min_shard(bp, sizes=(128, 256, 512, 1024, 2048), reps=5)
+    finally:
+        bp.close()
+    print("bf16 one-device call times (us):", {k: round(v, 1) for k, v in sorted(t.items())}, "-> min_shard", s)
+    assert s in (128, 256, 512, 1024, 2048)
+    assert s == 2048 or t[2 * s] > t[s] + 10.0

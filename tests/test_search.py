@@ -254,6 +254,26 @@ def test_search_does_the_same_thing_on_any_number_of_host_threads():
     assert runs[0][1]["eval_calls"] > 0 and runs[0][1]["boards_evaluated"] >= runs[0][1]["eval_calls"]
 
 
+def test_wide_batches_do_the_same_thing_on_any_number_of_host_threads():
+    """The same with batches large enough for the wide path (>= 320 nodes: the pool's second worker group, and from
+    four threads on the tree update on the evaluation lane beside the hand-over of the move scores and the arena
+    copy): value, move and every counter equal one thread's."""
+    runs = []
+    for threads in (1, 4, 8):
+        s = S.Search(max_batch_size=2048, tt_bits=18, threads=threads)
+        out = []
+        for fen in FENS[:3]:
+            value, move = s.iterative_deepening(fen, [1, 2, 3, 4])
+            out.append((value, tuple(int(x) for x in move)))
+        st = s.stats()
+        s.close()
+        assert st["wide_iterations"] > 10
+        assert (st["overlapped_updates"] > 10) == (threads >= 4), (threads, st["overlapped_updates"])
+        runs.append((out, {k: st[k] for k in ("iterations", "nodes_out", "nodes_in", "boards_evaluated", "moves_scored",
+                                              "max_batch", "eval_calls", "policy_calls", "wide_iterations", "arena_peak")}))
+    assert runs[0] == runs[1] == runs[2]
+
+
 def test_stage_times_add_up_to_the_search_time():
     s = S.Search(max_batch_size=512, tt_bits=16, threads=2)
     s.iterative_deepening(FENS[1], [1, 2, 3, 4])
@@ -276,3 +296,5 @@ def test_arena_limit_is_an_error_not_a_crash():
     s.close()
     with pytest.raises(RuntimeError, match="threads"):
         S.Search(threads=1000)
+    with pytest.raises(RuntimeError, match="max_nodes .* exceeds the limit"):   # node ids are ints
+        S.Search(max_nodes=2 ** 31)

@@ -1,6 +1,8 @@
 """The threaded search driver under ThreadSanitizer and AddressSanitizer + UBSan (host code only; the GPU pool has
 no sanitizer): the fork-join pool, the evaluation lane and the block arena run two depth-4 searches on four threads
-and the sanitizers must have nothing to report."""
+and the sanitizers must have nothing to report.  The searches must have taken the wide path (batches of 320 nodes
+or more: both worker groups of the pool, the tree update on the evaluation lane beside the hand-over of the move
+scores and the arena copy), which the driver reports."""
 import os
 import shutil
 import subprocess
@@ -28,3 +30,7 @@ def test_search_is_clean_under_host_sanitizers(tmp_path, flags):
     assert "runtime error" not in run.stderr
     lines = [l for l in run.stdout.splitlines() if l.startswith("value")]
     assert len(lines) == 2 and all(l.startswith("value 0.0 move ") for l in lines), lines   # material is level at depth 4
+    for l in lines:
+        words = l.split()
+        wide, overlapped = int(words[words.index("wide") + 1]), int(words[words.index("overlapped") + 1])
+        assert wide > 10 and overlapped > 10, l    # the wide path ran under the sanitizer

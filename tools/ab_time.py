@@ -38,7 +38,7 @@ def main():
     for spec in args.libs:
         name, path = spec.split("=", 1)
         env = {}
-        if "@" in path:     # name=lib.so@VAR=value: environment for the context's creation (e.g. BF_BF16_TILES=32)
+        if "@" in path:     # name=lib.so@VAR=value: environment for the context's creation (e.g. BF_T16_TWO_KERNELS=1)
             path, rest = path.split("@", 1)
             env = dict(kv.split("=", 1) for kv in rest.split("@"))
         os.environ.update(env)
