@@ -366,6 +366,7 @@ extern "C" int bf_ctx_create_ex(bf_ctx** out, int device, const float* h_weights
     if (precision == BF_PRECISION_BF16) {
         const char* two = std::getenv("BF_T16_TWO_KERNELS");
         c->two_kernels = two && std::strcmp(two, "1") == 0;
+
         std::vector<unsigned char> image(bf::t16::kImageBytes);
         bf::pack_weights_t16(h_weights, image.data());
         if (hipMalloc(&c->d_image16, image.size()) != hipSuccess)

@@ -53,10 +53,7 @@ constexpr int GR_ROWS = 12, GR_COLS = 24, GR_ROW0 = 2, GR_COL0 = 7;
 constexpr int GR_ENTRY = 32;             // two halves of 16 bytes
 constexpr int GR_ROW_BYTES = GR_COLS * GR_ENTRY;       // 768
 constexpr int GR_BYTES = GR_ROWS * GR_ROW_BYTES;       // 9216
-constexpr int XP_W = 10;                 // activation plane padded by 1
-constexpr int POS_BYTES = 64;            // 32 channels bf16
-constexpr int ROW_BYTES = XP_W * POS_BYTES;            // 640
-constexpr int PLANE_BYTES = XP_W * ROW_BYTES;          // 6400
+// (activation planes: XP_W, POS_BYTES, ROW_BYTES, PLANE_BYTES in t16_common.h)
 constexpr int BOARD_BYTES = 2 * PLANE_BYTES;
 static_assert(GR_BYTES <= BOARD_BYTES && GR_BYTES % 1024 == 0, "the one-hot image aliases the activation planes");
 

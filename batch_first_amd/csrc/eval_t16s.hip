@@ -26,15 +26,6 @@ namespace t16 {
 
 namespace {
 
-// One-hot image of the board, shared by the four waves: grid[rank -7 .. 14][file -7 .. 16][2 halves] of
-// 16-byte entries.  Every tap of every conv (up to 7 ranks / files away) of every square lands inside it, so a
-// unit's offset is a compile-time immediate on top of the lane's square whatever column tile the wave has.
-// Off-board entries are zeroed once per workgroup and never written; the 64 squares are overwritten per board.
-constexpr int SG_ROW0 = 7, SG_ROWS = 22, SG_COLS = 24, SG_COL0 = 7, SG_ENTRY = 32;
-constexpr int SG_ROW_BYTES = SG_COLS * SG_ENTRY;        // 768: three bank windows, the two ranks of a tile never meet in a bank
-constexpr int SG_BYTES = SG_ROWS * SG_ROW_BYTES;        // 16 896
-constexpr int XP_W = 10, POS_BYTES = 64, ROW_BYTES = XP_W * POS_BYTES, PLANE_BYTES = XP_W * ROW_BYTES;
-
 struct LdsS {
     f32x4 wring[SLOTS][CHUNK][64];                       // shared A-fragment ring, 64 KiB
     __attribute__((aligned(16))) unsigned char image[SG_BYTES];
@@ -59,47 +50,6 @@ struct WireArgs {
     unsigned start_nibble;
     int* err;                    // sticky malformed-input flag: 1 = stream too short, 2 = code 15
 };
-
-// ---- stage 1: units = (conv, k-step), every one computed ------------------------------------------------
-constexpr int kUnits = 39;
-struct S1Split {
-    int n;
-    short conv[kUnits + 1], g0[kUnits + 1];
-    int imm[kUnits + 1], da[kUnits + 1], db[kUnits + 1];
-    bool new_base[kUnits + 1], first_of_conv[kUnits + 1];
-};
-constexpr S1Split make_s1_split() {
-    S1Split T{};
-    int n = 0, g = 0;
-    for (int i = 0; i < kNumInputConvs; ++i)
-        for (int s = 0; s < steps_of(i); ++s) {
-            const TapPair tp = step_taps(i, s);
-            const int tb = tp.b >= 0 ? tp.b : tp.a;
-            const int off_a = ((tap_dr(i, tp.a) + SG_ROW0) * SG_COLS + tap_df(i, tp.a) + SG_COL0) * SG_ENTRY;
-            const int off_b = ((tap_dr(i, tb) + SG_ROW0) * SG_COLS + tap_df(i, tb) + SG_COL0) * SG_ENTRY;
-            T.conv[n] = (short)i;
-            T.g0[n] = (short)g;
-            T.imm[n] = off_a < off_b ? off_a : off_b;
-            T.da[n] = off_a - T.imm[n];
-            T.db[n] = off_b - T.imm[n];
-            T.new_base[n] = n == 0 || T.da[n] != T.da[n - 1] || T.db[n] != T.db[n - 1];
-            T.first_of_conv[n] = s == 0;
-            g += kRowTiles[i];
-            ++n;
-        }
-    T.n = n;
-    return T;
-}
-constexpr S1Split kS1s = make_s1_split();
-constexpr bool s1_split_in_grid() {
-    for (int u = 0; u < kS1s.n; ++u) {
-        // the furthest entry a lane reads: rank 7 + (2 * 3 + 1), file 7 of the unit's larger offset
-        const int hi = kS1s.imm[u] + (kS1s.da[u] > kS1s.db[u] ? kS1s.da[u] : kS1s.db[u]);
-        if (kS1s.imm[u] < 0 || hi + (7 * SG_COLS + 7) * SG_ENTRY + 2 * 16 > SG_BYTES || hi >= 65536) return false;
-    }
-    return true;
-}
-static_assert(kS1s.n == kUnits && s1_split_in_grid(), "every tap of every square lands inside the image");
 
 // MODE 0: scores; 2: features (x9 as float32 [board][32][64] into `out`); + 4: node records instead of mailboxes;
 // + 8: wire format (`wire`; src and src_stride unused).

@@ -16,8 +16,11 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BPB = 4;                   // boards per workgroup = waves per workgroup
-constexpr int WAVES = BPB;
+#ifndef T16_WAVES
+#define T16_WAVES 4
+#endif
+constexpr int BPB = 4;                   // boards per workgroup
+constexpr int WAVES = T16_WAVES;         // eval_t16.hip: one wave a board; eval_t16h.hip: two (eight waves a workgroup)
 constexpr int THREADS = 64 * WAVES;
 #ifndef T16_CHUNK
 #define T16_CHUNK 16
@@ -184,6 +187,57 @@ __device__ __forceinline__ unsigned pack_relu(float a, float b) {
 }
 __device__ __forceinline__ float bf16_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xFFFF0000u); }
+
+// ---- pieces shared by the kernels whose column tile is a run-time value (eval_t16s.hip, eval_t16h.hip) ----------
+// One-hot image of the board, shared by the waves of a board: grid[rank -7 .. 14][file -7 .. 16][2 halves] of
+// 16-byte entries.  Every tap of every conv (up to 7 ranks / files away) of every square lands inside it, so a
+// unit's offset is a compile-time immediate on top of the lane's square whatever column tile the wave has.
+// Off-board entries are zeroed once per workgroup and never written; the 64 squares are overwritten per board.
+constexpr int SG_ROW0 = 7, SG_ROWS = 22, SG_COLS = 24, SG_COL0 = 7, SG_ENTRY = 32;
+constexpr int SG_ROW_BYTES = SG_COLS * SG_ENTRY;        // 768: three bank windows, the two ranks of a tile never meet in a bank
+constexpr int SG_BYTES = SG_ROWS * SG_ROW_BYTES;        // 16 896
+constexpr int XP_W = 10, POS_BYTES = 64, ROW_BYTES = XP_W * POS_BYTES, PLANE_BYTES = XP_W * ROW_BYTES;
+
+// ---- stage 1: units = (conv, k-step), every one computed ------------------------------------------------
+constexpr int kUnits = 39;
+struct S1Split {
+    int n;
+    short conv[kUnits + 1], g0[kUnits + 1];
+    int imm[kUnits + 1], da[kUnits + 1], db[kUnits + 1];
+    bool new_base[kUnits + 1], first_of_conv[kUnits + 1];
+};
+constexpr S1Split make_s1_split() {
+    S1Split T{};
+    int n = 0, g = 0;
+    for (int i = 0; i < kNumInputConvs; ++i)
+        for (int s = 0; s < steps_of(i); ++s) {
+            const TapPair tp = step_taps(i, s);
+            const int tb = tp.b >= 0 ? tp.b : tp.a;
+            const int off_a = ((tap_dr(i, tp.a) + SG_ROW0) * SG_COLS + tap_df(i, tp.a) + SG_COL0) * SG_ENTRY;
+            const int off_b = ((tap_dr(i, tb) + SG_ROW0) * SG_COLS + tap_df(i, tb) + SG_COL0) * SG_ENTRY;
+            T.conv[n] = (short)i;
+            T.g0[n] = (short)g;
+            T.imm[n] = off_a < off_b ? off_a : off_b;
+            T.da[n] = off_a - T.imm[n];
+            T.db[n] = off_b - T.imm[n];
+            T.new_base[n] = n == 0 || T.da[n] != T.da[n - 1] || T.db[n] != T.db[n - 1];
+            T.first_of_conv[n] = s == 0;
+            g += kRowTiles[i];
+            ++n;
+        }
+    T.n = n;
+    return T;
+}
+constexpr S1Split kS1s = make_s1_split();
+constexpr bool s1_split_in_grid() {
+    for (int u = 0; u < kS1s.n; ++u) {
+        // the furthest entry a lane reads: rank 7 + (2 * 3 + 1), file 7 of the unit's larger offset
+        const int hi = kS1s.imm[u] + (kS1s.da[u] > kS1s.db[u] ? kS1s.da[u] : kS1s.db[u]);
+        if (kS1s.imm[u] < 0 || hi + (7 * SG_COLS + 7) * SG_ENTRY + 2 * 16 > SG_BYTES || hi >= 65536) return false;
+    }
+    return true;
+}
+static_assert(kS1s.n == kUnits && s1_split_in_grid(), "every tap of every square lands inside the image");
 
 #ifdef BF_STAMPS
 #define BF_STAMP(i) do { stamps[i] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)

@@ -17,7 +17,8 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
-constexpr int XP_W = 10, POS = 64, ROW = XP_W * POS, PLANE = XP_W * ROW;   // zero-haloed 10 x 10 x 32 bf16
+constexpr int XP_W = 10, POS = 64, ROW = XP_W * POS, PLANE = XP_W * 672;   // zero-haloed 10 x 10 x 32 bf16 (room for shape C's pitch)
+constexpr int ROWC = 672;
 constexpr int RING = 64;                                                  // fragments resident in LDS (64 KiB)
 
 __device__ __forceinline__ unsigned pack_relu(float a, float b) {
@@ -26,7 +27,12 @@ __device__ __forceinline__ unsigned pack_relu(float a, float b) {
     return u & ~((u >> 15) & 0x00010001u) * 0xFFFFu;   // a stand-in of the same length as the signed max
 }
 
-template <int TPW>   // tiles per wave: 4 (shape A) or 2 (shape B)
+// SHARED (shape C, round 3): shape A with a column tile = ranks (t, t + 4) instead of (2t, 2t + 1).  The B operand of tap
+// (dr, df) of tile t is then the pair of plane rows (t + dr, t + 4 + dr) = "virtual tile" v = t + dr, the same fragment
+// for (t, dr) = (v, 0), (v - 1, +1), (v + 1, -1): 6 virtual tiles x 3 file shifts = 18 B reads a chunk instead of 36,
+// kept in registers while three tiles use them.  The plane's row pitch is 672 bytes so that rows four apart fall into
+// different bank halves (4 x 672 = 10 x 256 + 128).
+template <int TPW, bool SHARED = false>   // tiles per wave: 4 (shape A) or 2 (shape B)
 __global__ __launch_bounds__(64 * 16 / TPW, 1) void k(float* out, int quads) {
     constexpr int WAVES = 16 / TPW;   // four boards a workgroup
     constexpr int WPB = 4 / TPW;      // waves per board
@@ -51,7 +57,47 @@ __global__ __launch_bounds__(64 * 16 / TPW, 1) void k(float* out, int quads) {
         for (int c = 0; c < 9; ++c) {
             const unsigned char* src = mine + (c & 1) * PLANE;
             unsigned char* dst = mine + ((c + 1) & 1) * PLANE;
-            if (TPW == 4) {
+            if (TPW == 4 && SHARED) {
+                const int waddrC = ((4 * rk + 1) * ROWC) + (file + 1) * POS + (((q + file + 1) & 3) << 4);   // tile 0's square; tile t one row up each
+                int raddrC[3];
+                for (int d = 0; d < 3; ++d) raddrC[d] = (4 * rk) * ROWC + (file + d) * POS + (((q + file + d) & 3) << 4);   // virtual tile -1
+                u32x4 bv[4][3];   // ring of four virtual tiles
+                bf16x8 f[18];
+                auto load_v = [&](int v) {   // v = -1 .. 4
+#pragma unroll
+                    for (int d = 0; d < 3; ++d)
+                        bv[(v + 1) & 3][d] = *reinterpret_cast<const u32x4*>(src + raddrC[d] + (v + 1) * ROWC);
+                };
+                load_v(-1); load_v(0); load_v(1);
+#pragma unroll
+                for (int n = 0; n < 36; ++n) {
+                    const int t = n / 9, tap = n % 9;
+                    if (t == 0) {
+                        f[2 * tap] = __builtin_bit_cast(bf16x8, rp[((c * 18 + 2 * tap) % RING) * 64]);
+                        f[2 * tap + 1] = __builtin_bit_cast(bf16x8, rp[((c * 18 + 2 * tap + 1) % RING) * 64]);
+                    }
+                    if (tap == 0 && t < 3) load_v(t + 2);   // for the next tile, a whole tile ahead
+                    const int v = t + tap / 3 - 1;
+                    const bf16x8 b = __builtin_bit_cast(bf16x8, bv[(v + 1) & 3][tap % 3]);
+                    acc[t][0] = MFMA16(f[2 * tap], b, acc[t][0]);
+                    acc[t][1] = MFMA16(f[2 * tap + 1], b, acc[t][1]);
+                    if (tap == 2 && t > 0) {
+                        u32x4 v4;
+                        v4.x = pack_relu(acc[t - 1][0][0], acc[t - 1][0][1]);
+                        v4.y = pack_relu(acc[t - 1][0][2], acc[t - 1][0][3]);
+                        v4.z = pack_relu(acc[t - 1][1][0], acc[t - 1][1][1]);
+                        v4.w = pack_relu(acc[t - 1][1][2], acc[t - 1][1][3]);
+                        *reinterpret_cast<u32x4*>(dst + waddrC + (t - 1) * ROWC) = v4;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                u32x4 v4;
+                v4.x = pack_relu(acc[3][0][0], acc[3][0][1]);
+                v4.y = pack_relu(acc[3][0][2], acc[3][0][3]);
+                v4.z = pack_relu(acc[3][1][0], acc[3][1][1]);
+                v4.w = pack_relu(acc[3][1][2], acc[3][1][3]);
+                *reinterpret_cast<u32x4*>(dst + waddrC + 3 * ROWC) = v4;
+            } else if (TPW == 4) {
                 // shape A: flat list of 36 slots (tile, tap), B six slots ahead, fragments of the chunk kept after tile 0
                 constexpr int D = 6;
                 u32x4 bq[D];
@@ -127,17 +173,17 @@ __global__ __launch_bounds__(64 * 16 / TPW, 1) void k(float* out, int quads) {
     out[blockIdx.x * 64 * WAVES + tid] = s;
 }
 
-template <int TPW>
+template <int TPW, bool SHARED = false>
 void run(const char* name) {
     const int blocks = 256, quads = 400;
     float* out;
     hipMalloc(&out, blocks * 1024 * sizeof(float));
-    hipLaunchKernelGGL((k<TPW>), dim3(blocks), dim3(64 * 16 / TPW), 0, 0, out, quads);
+    hipLaunchKernelGGL((k<TPW, SHARED>), dim3(blocks), dim3(64 * 16 / TPW), 0, 0, out, quads);
     hipDeviceSynchronize();
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL((k<TPW>), dim3(blocks), dim3(64 * 16 / TPW), 0, 0, out, quads);
+    hipLaunchKernelGGL((k<TPW, SHARED>), dim3(blocks), dim3(64 * 16 / TPW), 0, 0, out, quads);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms = 0;
@@ -153,7 +199,9 @@ void run(const char* name) {
 int main() {
     run<4>("A: one wave a board, four tiles a wave");
     run<2>("B: two waves a board, two tiles a wave");
+    run<4, true>("C: as A, 18 shared B reads a chunk");
     run<4>("A again");
     run<2>("B again");
+    run<4, true>("C again");
     return 0;
 }
