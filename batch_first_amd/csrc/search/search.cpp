@@ -158,8 +158,24 @@ struct bfs_search {
     std::vector<TTEntry> tt;
     u64 tt_mask = 0;
     Arena nodes;
-    std::vector<std::vector<int>> bins;
+    // (Insertion into the bins stays on one thread: handing every piece of the pool its share of the bins was
+    // measured in round 3 and took twice as long as one thread's appends, 8 against 4 % of a depth-5 search.)
+    struct Bin {
+        std::vector<int> v;
+    };
+    std::vector<Bin> bins;
     size_t in_bins = 0;
+    // Ancestry of the arena's nodes in four bytes each: (parent + 1) | terminated << 31.  The open list's validity
+    // check walks from every candidate to the root; in the 0.8 KB nodes every hop is a cache miss (14 % of a depth-5
+    // search), here the upper levels of the tree stay in cache.  Written where a node enters the arena and where
+    // the tree update terminates one; read only while no update runs.
+    // (calloc: max_nodes entries whose pages are only touched as the arena grows; never reallocated, because the tree
+    // update writes entries on the evaluation lane while the caller appends new ones)
+    struct FreeDeleter {
+        void operator()(uint32_t* p) const { std::free(p); }
+    };
+    std::unique_ptr<uint32_t[], FreeDeleter> up;
+    static constexpr uint32_t kDead = 0x80000000u;
     bfs_stats stats{};
     std::string error;
     size_t max_nodes = (size_t)1 << 22;
@@ -278,6 +294,7 @@ struct bfs_search {
                 n.best_value = std::max(value, n.best_value);
                 if (!(n.best_value >= n.separator || n.children_left == 0)) return;
                 n.terminated = true;
+                up[id] |= kDead;
                 tt_add(n, following);
                 value = -n.best_value;
                 following = n.prev_move;
@@ -288,9 +305,12 @@ struct bfs_search {
     }
 
     bool should_not_terminate(int id) const {  // global_open_priority_nodes.py:4-11
-        for (; id >= 0; id = nodes[id].parent)
-            if (nodes[id].terminated) return false;
-        return true;
+        for (;;) {
+            const uint32_t u = up[id];
+            if (u & kDead) return false;
+            if (u == 0) return true;   // the root
+            id = (int)(u - 1);
+        }
     }
 
     // can_draw_from_repetition, numba_negamax_zero_window.py:109-149 (no pre-search game history)
@@ -479,20 +499,24 @@ struct bfs_search {
     }
 
     void clear_bins() {
-        for (auto& b : bins) b.clear();
+        for (auto& b : bins) b.v.clear();
         in_bins = 0;
     }
 
     // Appends to `batch` those of cand[from..) that are still worth expanding, in order; the checks (a walk up
     // the ancestors, read-only) run on the pool.
     void keep_live(const std::vector<int>& cand_ids, size_t from, std::vector<int>* batch) {
+        const double tl = now();
         const size_t n = cand_ids.size() - from;
         live.resize(n);
         par(n, grain(n), [&](size_t b, size_t e) {
             for (size_t i = b; i < e; ++i) live[i] = should_not_terminate(cand_ids[from + i]) ? 1 : 0;
         });
+        const double tm = now();
         for (size_t i = 0; i < n; ++i)
             if (live[i]) batch->push_back(cand_ids[from + i]);
+        stats.select_pop_seconds += now() - tm;
+        stats.select_live_seconds += tm - tl;
     }
 
     // insert_nodes + get_batch (global_open_priority_nodes.py:73-121,143-177).  Nodes leave the bins in the same order
@@ -504,7 +528,8 @@ struct bfs_search {
         std::vector<int> batch;
         cand.clear();
         if (ids.size() + in_bins < cfg.max_batch_size) {
-            for (auto& b : bins) {
+            for (auto& bin : bins) {
+                auto& b = bin.v;
                 cand.insert(cand.end(), b.rbegin(), b.rend());
                 b.clear();
             }
@@ -512,18 +537,21 @@ struct bfs_search {
             cand.insert(cand.end(), ids.begin(), ids.end());
             keep_live(cand, 0, &batch);
         } else {
+            const double ti = now();
             bin_idx.resize(ids.size());
             par(ids.size(), 4 * grain(ids.size()), [&](size_t b, size_t e) {
                 for (size_t i = b; i < e; ++i) bin_idx[i] = (unsigned)bin_of(scores[i]);
             });
-            for (size_t i = 0; i < ids.size(); ++i) bins[bin_idx[i]].push_back(ids[i]);
+            for (size_t i = 0; i < ids.size(); ++i) bins[bin_idx[i]].v.push_back(ids[i]);
             in_bins += ids.size();
+            stats.select_insert_seconds += now() - ti;
             size_t bin = 0;
             while (batch.size() < cfg.max_batch_size && in_bins > 0) {
+                const double tp = now();
                 const size_t from = cand.size();
                 size_t need = cfg.max_batch_size - batch.size();
                 while (need > 0 && bin < bins.size()) {
-                    auto& b = bins[bin];
+                    auto& b = bins[bin].v;
                     if (b.empty()) {
                         ++bin;
                         continue;
@@ -535,6 +563,7 @@ struct bfs_search {
                     in_bins -= k;
                     need -= k;
                 }
+                stats.select_pop_seconds += now() - tp;
                 if (cand.size() == from) break;
                 keep_live(cand, from, &batch);
             }
@@ -729,6 +758,7 @@ struct bfs_search {
             return fail("search arena would exceed its limit of %zu nodes (bfs_config.max_nodes)", max_nodes);
         nodes.resize(base + kept.size());   // may throw; LanesJoined joins the update before the exception leaves
         stats.arena_peak = std::max<uint64_t>(stats.arena_peak, nodes.size());
+        const double tc = now();
         par(kept.size(), grain(kept.size()), [&](size_t b, size_t e) {
             for (size_t i = b; i < e; ++i) {
                 const Node& src = fresh[kept[i]];
@@ -740,10 +770,12 @@ struct bfs_search {
                         __builtin_prefetch(p + off, 1);
                 }
                 std::memcpy(static_cast<void*>(&dst), static_cast<const void*>(&src), offsetof(Node, moves));
+                up[base + i] = (uint32_t)(src.parent + 1);   // open children are not terminated
                 std::memcpy(dst.moves, src.moves, src.n_moves * sizeof(Move));
                 std::memcpy(dst.move_scores, src.move_scores, src.n_moves * sizeof(float));
             }
         });
+        stats.compact_copy_seconds += now() - tc;
         for (size_t i = 0; i < kept.size(); ++i) {
             to_insert->push_back((int)(base + i));
             insert_scores->push_back(first_score[i]);
@@ -771,6 +803,7 @@ struct bfs_search {
         r.next_move_index = kNoMoreMoves;
         r.children_left = 0;
         r.prev_move = kNoMove;
+        up[0] = 0;
         if (depth == 0) {
             // the reference never searches to depth 0; give the evaluation so callers get a value
             if (settle(r)) {
@@ -1073,7 +1106,18 @@ extern "C" int bfs_search_create(bfs_search** out, const bfs_config* cfg) {
         return fail("bfs_search_create: threads %d out of range 0..256", cfg->threads);
     }
     int threads = cfg->threads;
-    if (threads == 0) threads = (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    if (threads == 0) {
+        // Beside the pool run the caller's thread (part of it), the two evaluator lanes and the GPU runtime's own
+        // threads: with every core given to the pool the lanes lose theirs (depth 5 on 16 cores: 12 threads 7.8 M
+        // nodes/s, 15 threads 5.7 M, profiles/r2/search).  Cores: OMP_NUM_THREADS where a scheduler sets it to the
+        // job's share of the machine (hardware_concurrency reports the whole machine there), else what the machine has.
+        unsigned cores = std::max(1u, std::thread::hardware_concurrency());
+        if (const char* e = std::getenv("OMP_NUM_THREADS")) {
+            const unsigned long v = std::strtoul(e, nullptr, 10);
+            if (v >= 1 && v < cores) cores = (unsigned)v;
+        }
+        threads = (int)std::min(16u, cores > 5 ? cores - 4 : std::max(1u, cores / 2));
+    }
     if (cfg->max_nodes > (size_t)INT_MAX) {   // node ids (parent links, the open list) are ints
         delete s;
         return fail("bfs_search_create: max_nodes %zu exceeds the limit of %d", cfg->max_nodes, INT_MAX);
@@ -1082,6 +1126,8 @@ extern "C" int bfs_search_create(bfs_search** out, const bfs_config* cfg) {
     try {
         s->tt.assign((size_t)1 << cfg->tt_bits, TTEntry());
         s->nodes.reserve_blocks(s->max_nodes);
+        s->up.reset(static_cast<uint32_t*>(std::calloc(s->max_nodes + 1, sizeof(uint32_t))));
+        if (!s->up) throw std::bad_alloc();
         s->pool.reset(new Pool(threads));       // runs with the workers it could start
         s->eval_lane.reset(new Lane());
         s->policy_lane.reset(new Lane());

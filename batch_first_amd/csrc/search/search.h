@@ -47,7 +47,9 @@ typedef struct {
     size_t max_nodes;           // arena limit in nodes (0.8 KB each), checked before the arena grows; 0 = 2^22 (3.5 GB);
                                 // at most INT_MAX (node ids are ints): more is refused by bfs_search_create
     int threads;                // host threads for the per-node loops of a batch (the reference's prange,
-                                // numba_board.py:242-266); 0 = min(8, hardware threads); results do not depend on it
+                                // numba_board.py:242-266); 0 = the job's cores (OMP_NUM_THREADS if set, else the
+                                // machine's) minus four for the caller, the evaluator lanes and the GPU runtime, at
+                                // most 16; results do not depend on it
 } bfs_config;
 
 typedef struct {
@@ -72,6 +74,10 @@ typedef struct {
     double select_seconds;      // open list: insert_and_get_batch
     uint64_t arena_peak;        // most nodes the arena held at once
     double update_busy_seconds; // the tree update's own time (overlaps policy_seconds and compact_seconds)
+    // inside select_seconds: binning + insertion, taking candidates off the bins, the candidates' validity checks
+    double select_insert_seconds, select_pop_seconds, select_live_seconds;
+    // inside compact_seconds: the copy of the open children to the arena
+    double compact_copy_seconds;
     uint64_t wide_iterations;   // batches of at least `wide_batch` nodes: their loops ran on every pool thread
     uint64_t overlapped_updates;// of which the tree update ran on the evaluation lane beside the hand-over of the
                                 // move scores and the arena copy (four host threads or more)

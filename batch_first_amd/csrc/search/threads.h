@@ -67,6 +67,17 @@ private:
 // ones.  A search at shallow depth hands over a hundred nodes forty thousand times a second: a dozen workers that
 // all spin for those jobs gain nothing on three and take the cores that the evaluator's threads need (depth 4:
 // 3.2 M nodes/s with twelve threads, 3.7 M with two); while only narrow jobs come, the second group goes to sleep.
+//
+// A job ends when all its ITEMS are done, not when every worker has reported: a worker that is asleep or that the
+// operating system has taken off its core (the box runs the evaluators' threads and the GPU runtime's beside the
+// pool) arrives late, finds nothing left and goes back to waiting, and nobody waited for it.  (Round 2's pool counted
+// workers: on a busy box every hand-over then cost the slowest worker's wake-up, and the open list's validity check
+// took four times as long on eight threads as on one.)  Pieces are claimed by compare-and-swap on a word that
+// carries the job's number, and jobs alternate between two descriptions: a late worker that still holds job g's
+// word reads description g & 1, which nobody rewrites before job g + 1 has been published (after which its
+// compare-and-swap fails); while the word still says "job g, everything claimed" the description is intact and tells
+// it that nothing is left.  (With ONE description the worker could read the next job's larger item count beside the
+// old word and claim a piece that does not exist yet: the first version of this pool hung that way.)
 class Pool {
 public:
     // threads = total including the caller; workers that cannot be started are done without
@@ -100,35 +111,49 @@ public:
             return;
         }
         struct Ctx { F* f; } ctx{&f};
-        call_ = [](void* c, size_t b, size_t e) { (*static_cast<Ctx*>(c)->f)(b, e); };
-        ctx_ = &ctx;
-        total_ = n;
-        grain_ = grain;
-        next_.store(0);
-        const bool second = wide && in_group_[1] > 0;
-        remaining_.store(in_group_[0] + (second ? in_group_[1] : 0));
+        // the job's description is written before its number is published and stays untouched until its last item
+        // is done; a piece can only be claimed while the job is unfinished (see run_pieces)
+        const uint64_t job = ++job_;
+        Desc& d = desc_[job & 1];
+        d.call.store([](void* c, size_t b, size_t e) { (*static_cast<Ctx*>(c)->f)(b, e); }, std::memory_order_relaxed);
+        d.ctx.store(&ctx, std::memory_order_relaxed);
+        d.total.store(n, std::memory_order_relaxed);
+        d.grain.store(grain, std::memory_order_relaxed);
+        done_.store(0, std::memory_order_relaxed);
+        next_.store(job << 32, std::memory_order_release);
         start_[0].bump();
-        if (second) start_[1].bump();
-        drain();
-        while (remaining_.load() != 0) cpu_relax();
+        if (wide && in_group_[1] > 0) start_[1].bump();
+        run_pieces();
+        while (done_.load(std::memory_order_acquire) != n) cpu_relax();
     }
 
 private:
-    void drain() {
+    void run_pieces() {
         for (;;) {
-            const size_t b = next_.fetch_add(grain_);
-            if (b >= total_) return;
-            call_(ctx_, b, b + grain_ < total_ ? b + grain_ : total_);
+            uint64_t cur = next_.load(std::memory_order_acquire);
+            // (relaxed atomics: a worker that is two jobs late may read these while the caller rewrites them; its
+            // claim below then fails, and what it read is dropped)
+            const Desc& d = desc_[(cur >> 32) & 1];
+            const size_t total = d.total.load(std::memory_order_relaxed), grain = d.grain.load(std::memory_order_relaxed);
+            const CallFn call = d.call.load(std::memory_order_relaxed);
+            void* const ctx = d.ctx.load(std::memory_order_relaxed);
+            const size_t b = (size_t)(cur & 0xFFFFFFFFull);
+            if (b >= total) return;
+            const size_t e = b + grain < total ? b + grain : total;
+            // succeeds only if nobody has claimed [b, e) of THIS job: the job is then unfinished, so what was read
+            // above is its description
+            if (!next_.compare_exchange_weak(cur, (cur & ~0xFFFFFFFFull) | e, std::memory_order_acq_rel)) continue;
+            call(ctx, b, e);
+            done_.fetch_add(e - b, std::memory_order_release);
         }
     }
     void worker(int group) {
         uint64_t seen = 0;
         for (;;) {
             start_[group].wait_change(seen);
-            seen = start_[group].value();   // one job at a time: the caller waits for every worker it woke before the next bump
+            seen = start_[group].value();
             if (stop_.load()) return;
-            drain();
-            remaining_.fetch_sub(1);
+            run_pieces();
         }
     }
 
@@ -136,11 +161,16 @@ private:
     int in_group_[2] = {0, 0};
     Gate start_[2];
     std::atomic<bool> stop_{false};
-    std::atomic<size_t> next_{0};
-    std::atomic<int> remaining_{0};
-    size_t total_ = 0, grain_ = 1;
-    void (*call_)(void*, size_t, size_t) = nullptr;
-    void* ctx_ = nullptr;
+    std::atomic<uint64_t> next_{0};   // job number << 32 | first unclaimed index
+    std::atomic<size_t> done_{0};     // items of the current job that are finished
+    uint64_t job_ = 0;
+    using CallFn = void (*)(void*, size_t, size_t);
+    struct Desc {
+        std::atomic<size_t> total{0}, grain{1};
+        std::atomic<CallFn> call{nullptr};
+        std::atomic<void*> ctx{nullptr};
+    };
+    Desc desc_[2];
 };
 
 // One thread that runs the calls handed to it, in order; wait() returns when all of them are done.

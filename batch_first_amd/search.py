@@ -38,7 +38,9 @@ class Stats(_c.Structure):
                 ("policy_calls", _c.c_uint64), ("expand_seconds", _c.c_double), ("settle_seconds", _c.c_double),
                 ("policy_seconds", _c.c_double), ("value_wait_seconds", _c.c_double), ("update_seconds", _c.c_double),
                 ("compact_seconds", _c.c_double), ("select_seconds", _c.c_double), ("arena_peak", _c.c_uint64),
-                ("update_busy_seconds", _c.c_double), ("wide_iterations", _c.c_uint64),
+                ("update_busy_seconds", _c.c_double), ("select_insert_seconds", _c.c_double),
+                ("select_pop_seconds", _c.c_double), ("select_live_seconds", _c.c_double), ("compact_copy_seconds", _c.c_double),
+                ("wide_iterations", _c.c_uint64),
                 ("overlapped_updates", _c.c_uint64)]
 
     def as_dict(self):
@@ -183,7 +185,8 @@ class Search:
                  max_batch_size=5000, tt_bits=22, bin_edges=None, bin_zero_shift=0.0, eval_zero_shift=0.0,
                  max_nodes=0, threads=0):
         """max_nodes: limit of the node arena (0 = 2^22 nodes, 3.5 GB); a search that would pass it fails
-        with an error instead of growing.  threads: host threads for the per-node loops of a batch (0 = up to 8);
+        with an error instead of growing.  threads: host threads for the per-node loops of a batch (0 = the job's cores
+        minus four, at most 16);
         results do not depend on it."""
         self._lib = load()
         if bin_edges is None:

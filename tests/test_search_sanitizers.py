@@ -34,3 +34,19 @@ def test_search_is_clean_under_host_sanitizers(tmp_path, flags):
         words = l.split()
         wide, overlapped = int(words[words.index("wide") + 1]), int(words[words.index("overlapped") + 1])
         assert wide > 10 and overlapped > 10, l    # the wide path ran under the sanitizer
+
+
+def test_pool_visits_every_index_once_under_thread_sanitizer(tmp_path):
+    """The fork-join pool ends a job when its ITEMS are done and lets late workers find nothing (threads.h): many short
+    jobs of changing size, narrow and wide, on eight threads under ThreadSanitizer; every index exactly once."""
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "pool_stress")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=thread", "-I", SRC,
+                    os.path.join(ROOT, "tests", "pool_stress_driver.cpp"), "-o", exe], check=True, capture_output=True, timeout=300)
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66")
+    env.pop("LD_PRELOAD", None)
+    run = subprocess.run([exe, "8", "20000"], capture_output=True, text=True, timeout=600, env=env)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "WARNING: ThreadSanitizer" not in run.stderr
+    assert run.stdout.strip().endswith("bad 0")
