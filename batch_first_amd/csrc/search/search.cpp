@@ -404,6 +404,13 @@ struct bfs_search {
     }
     FinishCall finish_call{};
     bool finish_pending = false;
+    // stage 1 (copy the records in, launch) also runs on the policy lane: the call takes 20-30 us on whoever makes it,
+    // a tenth of a depth-5 iteration, and the caller packs the move lists meanwhile.  The lane runs its calls in
+    // order, so the finish call handed over after the packing finds stage 1 started.
+    static int run_start(void* arg) {
+        bfs_search* s = static_cast<bfs_search*>(arg);
+        return s->cfg.move_start(s->cfg.move_user, s->policy_recs.data(), sizeof(EvalRecord), nullptr, s->policy_recs.size());
+    }
 
     int score_begin(const std::vector<Node*>& who) {
         finish_pending = false;
@@ -429,10 +436,8 @@ struct bfs_search {
                 for (size_t i = b; i < e; ++i) to_record(who[i]->b, &policy_recs[i]);
             });
             ++stats.policy_calls;
-            const double tw = now();
-            if (cfg.move_start(cfg.move_user, policy_recs.data(), sizeof(EvalRecord), nullptr, policy_recs.size()))
-                return fail("the move-scoring network's start call failed");
-            stats.eval_wait_seconds += now() - tw;
+            policy_lane->submit(&run_start, this);
+            finish_pending = true;   // (the lane has work of this batch: score_end or LanesJoined waits for it)
         } else {
             for (size_t i = 0; i < total; ++i) scores[i] = total > 1 ? (float)((double)i / (double)(total - 1)) : 0.0f;
         }
@@ -469,7 +474,7 @@ struct bfs_search {
             const double tw = now();
             const int rc = policy_lane->wait();
             stats.eval_wait_seconds += now() - tw;
-            if (rc) return fail("the move-scoring network's finish call failed");
+            if (rc) return fail("the move-scoring network's start or finish call failed");
         }
         if (who.empty()) return 0;
         const float* scores = move_scores_buf.data();
