@@ -32,17 +32,25 @@ PEAK_HBM_GBS = 8000.0
 # under profiles/ (FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes; see
 # tools/pmc_summary.py).  Counters cannot be read from inside this process, so the figure is the
 # committed measurement of the same kernel and batch, not a live one.
-TRAFFIC_PROFILES = {"f32": "profiles/r2/pmc_k_eval_f32_r2f.json", "bf16": "profiles/r2/pmc_k_eval_t16_r2f.json"}
+# Round 3: the passes are taken with the kernel ALONE in the process (tools/kernel_only.py, tools/pmc_alone.sh: no
+# other kernel's dirty lines in the figure) and the file records a hash of the kernel's sources; the bench line says
+# whether that hash is the one of the sources this tree holds ("traffic_matches_sources").
+TRAFFIC_PROFILES = {"f32": "profiles/r3/pmc_alone_f32.json", "bf16": "profiles/r3/pmc_alone_bf16.json"}
 BF16_KERNEL = "k_eval_t16"
 
 
 def profiled_traffic(dtype):
+    """(bytes per launch, file, does the file belong to this tree's kernel sources)"""
     path = os.path.join(ROOT, TRAFFIC_PROFILES[dtype])
     try:
         with open(path) as fh:
-            return float(json.load(fh)["hbm_bytes_per_launch"]["total"]), TRAFFIC_PROFILES[dtype]
-    except (OSError, KeyError, ValueError):
-        return None, None
+            d = json.load(fh)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from kernel_only import source_sha16
+        m = d["hbm_bytes_per_launch_median"]
+        return float(m["read"] + m["write"]), TRAFFIC_PROFILES[dtype], d.get("source_sha16") == source_sha16(dtype)
+    except (OSError, KeyError, ValueError, ImportError):
+        return None, None, None
 
 
 def cpu_baseline(budget_s=12.0):
@@ -157,7 +165,10 @@ def main():
     def measure(dtype):
         """The timed region of the contract (W warm-up steps, exactly K steps between fences, MAX over
         ranks) and then the dominant kernel alone, for one precision.  Returns (elapsed seconds of the K
-        steps, kernel ms per 65 536-board launch, the context)."""
+        steps, kernel ms per 65 536-board launch, the context).  The kernel figure is that of the kernel the timed
+        step launches: for bf16 the record-in form of k_eval_t16 (one launch a step; the mailbox-in form, which a
+        round-2 line quoted, is given beside it), for fp32 k_eval_f32 (the step's other launch is the 2 MB record ->
+        mailbox kernel)."""
         ctx = ops.DeviceContext(w, device=dev_index, dtype=dtype)
 
         def step():
@@ -194,11 +205,22 @@ def main():
             torch.ops.batchfirst.eval_mailbox(ctx.handle, mailbox)
         ev1.record()
         torch.cuda.synchronize()
-        return elapsed, ev0.elapsed_time(ev1) / reps, ctx
+        mailbox_ms = ev0.elapsed_time(ev1) / reps
+        if dtype != "bf16":
+            return elapsed, mailbox_ms, None, ctx
+        for _ in range(reps):
+            torch.ops.batchfirst.eval_structs(ctx.handle, krecs)
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(reps):
+            torch.ops.batchfirst.eval_structs(ctx.handle, krecs)
+        ev1.record()
+        torch.cuda.synchronize()
+        return elapsed, ev0.elapsed_time(ev1) / reps, mailbox_ms, ctx
 
     bf16 = args.dtype == "bf16"
     peak_tflops = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
-    elapsed, kernel_ms, ctx = measure(args.dtype)
+    elapsed, kernel_ms, kernel_ms_mailbox_in, ctx = measure(args.dtype)
     total_boards = (1 << 24) if shard else world * n
     n_kernel = 65536 if shard else n
     achieved_tflops = spec.FLOPS_PER_BOARD * n_kernel / (kernel_ms * 1e-3) / 1e12
@@ -206,15 +228,18 @@ def main():
     # kernel on the same records (the headline fields above stay those of --dtype)
     other = None
     if not bf16:
-        o_elapsed, o_kernel_ms, o_ctx = measure("bf16")
+        o_elapsed, o_kernel_ms, o_mailbox_ms, o_ctx = measure("bf16")
         o_tflops = spec.FLOPS_PER_BOARD * n_kernel / (o_kernel_ms * 1e-3) / 1e12
-        o_traffic, o_src = profiled_traffic("bf16")
+        o_traffic, o_src, o_match = profiled_traffic("bf16")
         other = {"value": total_boards * args.steps / o_elapsed, "unit": "boards/s", "steps": args.steps, "warmup": args.warmup,
                  "ms_per_step": 1e3 * o_elapsed / args.steps, "dtype": "bf16",
                  "config": {"workload": "BASELINE configs[2] kernel (bf16 operands, fp32 sums) on the headline's records and batch"},
-                 "roofline": {"bound": "mfma", "kernel": BF16_KERNEL, "achieved": o_tflops, "peak": PEAK_BF16_MFMA_TFLOPS,
+                 "roofline": {"bound": "mfma", "kernel": BF16_KERNEL + "<4> (node records in: the kernel the timed step launches)",
+                              "achieved": o_tflops, "peak": PEAK_BF16_MFMA_TFLOPS,
                               "unit": "TFLOP/s", "frac": o_tflops / PEAK_BF16_MFMA_TFLOPS, "kernel_ms": o_kernel_ms,
-                              "traffic": o_traffic, "traffic_source": o_src, "flops_per_board": spec.FLOPS_PER_BOARD}}
+                              "kernel_ms_mailbox_in": o_mailbox_ms,
+                              "traffic": o_traffic, "traffic_source": o_src, "traffic_matches_sources": o_match,
+                              "flops_per_board": spec.FLOPS_PER_BOARD}}
         o_ctx.close()
     if shard:
         recs = recs[:65536].contiguous()
@@ -255,7 +280,7 @@ def main():
     enc_gbs = n * (88 + 3840) / (enc_ms * 1e-3) / 1e9
     del planes
 
-    traffic, traffic_src = profiled_traffic(args.dtype)
+    traffic, traffic_src, traffic_match = profiled_traffic(args.dtype)
     if rank == 0:
         value = total_boards * args.steps / elapsed
         out = {
@@ -278,10 +303,12 @@ def main():
                        "per_gpu_batch": ((1 << 24) // world) if shard else n,
                        "global_batch": total_boards,
                        "parallelism": "independent shards per GPU" + (", RCCL gather of scores to rank 0" if world > 1 else "")},
-            "roofline": {"bound": "mfma", "kernel": BF16_KERNEL if bf16 else "k_eval_f32", "achieved": achieved_tflops,
+            "roofline": {"bound": "mfma", "kernel": (BF16_KERNEL + "<4> (node records in)") if bf16 else "k_eval_f32", "achieved": achieved_tflops,
                          "peak": peak_tflops, "unit": "TFLOP/s", "frac": achieved_tflops / peak_tflops,
-                         "traffic": traffic, "traffic_unit": "bytes per launch (HBM, PMC)", "traffic_source": traffic_src,
-                         "algorithmic_bytes": n * (32 + 4), "kernel_ms": kernel_ms,
+                         "traffic": traffic, "traffic_unit": "bytes per launch (HBM, PMC, kernel alone in the process)",
+                         "traffic_source": traffic_src, "traffic_matches_sources": traffic_match,
+                         "algorithmic_bytes": n * ((88 if bf16 else 32) + 4), "kernel_ms": kernel_ms,
+                         **({"kernel_ms_mailbox_in": kernel_ms_mailbox_in} if bf16 else {}),
                          "flops_per_board": spec.FLOPS_PER_BOARD},
             "encode_roofline": {"bound": "hbm", "kernel": "k_to_planes<StructSrc>", "achieved": enc_gbs,
                                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": enc_gbs / PEAK_HBM_GBS,

@@ -380,3 +380,27 @@ def test_multi_device_callable_equals_single_device(torch_mod, golden, dtype):
 def D_shard(n, r, parts):
     from batch_first_amd.distributed import shard_range
     return shard_range(n, r, parts)[0]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_evaluate_sharded_with_the_real_evaluator_world_size_one(torch_mod, golden, dtype):
+    """batch_first_amd.distributed.evaluate_sharded (what bench.py's ranks do: this rank's contiguous shard through
+    the HIP evaluator, scores gathered to rank 0) in a world of one process on the GPU box: the shard is everything,
+    the gather is the identity, the scores are the single-context ones bit for bit.  (World sizes 2 and 3, ragged
+    shards and odd-nibble wire shards run on gloo with a host evaluator in tests/test_distributed_cpu.py.)"""
+    import socket
+    import torch.distributed as dist
+    from batch_first_amd import distributed as D, ops
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    ctx = ops.DeviceContext(W.make_weights(seed=1234, bn="perturbed"), device=0, dtype=dtype)
+    try:
+        recs = torch_mod.from_numpy(golden["records"].copy()).cuda()
+        want = torch_mod.ops.batchfirst.eval_structs(ctx.handle, recs).cpu()
+        got = D.evaluate_sharded(lambda r: torch_mod.ops.batchfirst.eval_structs(ctx.handle, r).cpu(), recs, dst=0)
+        assert got.shape == (1024,) and torch_mod.equal(got, want)
+        ragged = D.evaluate_sharded(lambda r: torch_mod.ops.batchfirst.eval_structs(ctx.handle, r).cpu(), recs[:777], dst=0)
+        assert torch_mod.equal(ragged, want[:777])
+    finally:
+        ctx.close()
+        dist.destroy_process_group()

@@ -29,11 +29,16 @@ def main():
                     per_dispatch[key] = per_dispatch.get(key, 0.0) + float(row["Counter_Value"])
             for (name, _), v in per_dispatch.items():
                 counters.setdefault(name, []).append(v)
-    summary = {name: {"launches": len(v), "mean_per_launch": sum(v) / len(v)} for name, v in sorted(counters.items())}
+    summary = {name: {"launches": len(v), "mean_per_launch": sum(v) / len(v), "median_per_launch": sorted(v)[len(v) // 2],
+                      "min_per_launch": min(v), "max_per_launch": max(v)} for name, v in sorted(counters.items())}
     out = {"kernel": kernel, "counters": summary}
+    if os.environ.get("PMC_SOURCE_SHA16"):   # tools/kernel_only.py: hash of the kernel's sources the counters belong to
+        out["source_sha16"] = os.environ["PMC_SOURCE_SHA16"]
     if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
         rd = 2.0 * summary["FETCH_SIZE"]["mean_per_launch"] * 1024.0
         wr = summary["WRITE_SIZE"]["mean_per_launch"] * 1024.0
+        out["hbm_bytes_per_launch_median"] = {"read": 2.0 * summary["FETCH_SIZE"]["median_per_launch"] * 1024.0,
+                                              "write": summary["WRITE_SIZE"]["median_per_launch"] * 1024.0}
         out["hbm_bytes_per_launch"] = {"read": rd, "write": wr, "total": rd + wr,
                                        "correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950 wide reads), WRITE_SIZE KiB x 1024"}
     if "TCC_HIT_sum" in summary and "TCC_MISS_sum" in summary:
