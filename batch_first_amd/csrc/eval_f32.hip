@@ -274,10 +274,26 @@ __device__ __forceinline__ void conv3x3_chunk(WStream& ws, int g0, const float* 
     }
 }
 
+// Two bf16 terms of a pair of float32 values, packed (a low, b high): hi = bf16(x) to nearest-even,
+// mid = bf16(x - hi); hi + mid carries 16 significant bits of x.
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& mid) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+    const float ra = a - __builtin_bit_cast(float, hi << 16);
+    const float rb = b - __builtin_bit_cast(float, hi & 0xFFFF0000u);
+    mid = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{ra, rb}, bf16x2));
+}
+#define BF_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
+
 // MODE 0: scores; 1: scores + every intermediate activation (debug); 2: features -- x9, the
 // activations after the six 3x3 layers, as float32 [board][32][64] into `scores`, no head (the
 // move-scoring network, whose 1x1 logit layer is applied per requested move by k_policy_scores).
-template <int MODE>
+// SPLIT (BF_PRECISION_F32_SPLIT, include/batchfirst.h): the 1x1 pair, 68 % of the network's FLOPs, runs on
+// v_mfma_f32_32x32x16_bf16 with both operands as TWO bf16 terms (16 significant bits) and all four products,
+// float32 sums: 92 32-cycle MFMAs a hidden tile instead of 183 64-cycle ones.  Everything else is this kernel
+// unchanged.  Same stream shape (30 + 16 groups a hidden tile), other contents: pack.cpp.
+template <int MODE, bool SPLIT>
 __global__ __launch_bounds__(THREADS, 2) void k_eval_f32(const uint8_t* __restrict__ mailbox, unsigned n_boards,
                                                           const f32x4* __restrict__ wstream,
                                                           const float* __restrict__ bias,
@@ -348,6 +364,52 @@ __global__ __launch_bounds__(THREADS, 2) void k_eval_f32(const uint8_t* __restri
         for (int t = 0; t < 16; ++t)
             acc3[c3][t] = pick(hl, bias[kBiasX3 + 32 * c3 + rowmap(t, 0)], bias[kBiasX3 + 32 * c3 + rowmap(t, 1)]);
 
+    if (SPLIT) {
+        // x1 as two bf16 terms, packed for the B operand of v_mfma_f32_32x32x16_bf16: k-step s takes registers
+        // 8s .. 8s+7 (element j of lane half h = channel 16s + 2j + h); register 118 of half 0 is the all-ones slot
+        // that carries the hidden layer's shift, the rest of the padding is zero.
+        unsigned xs[2][60];
+#pragma unroll
+        for (int d = 0; d < 60; ++d) {
+            const float a = 2 * d < kX1Regs ? x1[2 * d] : (2 * d == kX1Regs ? pick(hl, 1.0f, 0.0f) : 0.0f);
+            const float b = 2 * d + 1 < kX1Regs ? x1[2 * d + 1] : 0.0f;
+            split2(a, b, xs[0][d], xs[1][d]);
+        }
+#pragma unroll 1
+        for (int it = 0; it < kC2Tiles / C2_UNROLL; ++it) {
+#pragma unroll
+            for (int u = 0; u < C2_UNROLL; ++u) {
+                const int g0 = kInputGroups + u * kPerC2Groups;
+                f32x16 acc2 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 15; ++s) {
+                    const f32x4 wh = ws.take(g0 + 2 * s), wm = ws.take(g0 + 2 * s + 1);
+                    const u32x4 xh = u32x4{xs[0][4 * s], xs[0][4 * s + 1], xs[0][4 * s + 2], xs[0][4 * s + 3]};
+                    const u32x4 xm = u32x4{xs[1][4 * s], xs[1][4 * s + 1], xs[1][4 * s + 2], xs[1][4 * s + 3]};
+                    acc2 = BF_MFMA16(wm, xm, acc2);
+                    acc2 = BF_MFMA16(wm, xh, acc2);
+                    acc2 = BF_MFMA16(wh, xm, acc2);
+                    acc2 = BF_MFMA16(wh, xh, acc2);
+                }
+                // ReLU, then the hidden tile as two bf16 terms: k-step v takes registers 8v .. 8v+7
+                unsigned hs[2][8];
+#pragma unroll
+                for (int d = 0; d < 8; ++d) split2(relu(acc2[2 * d]), relu(acc2[2 * d + 1]), hs[0][d], hs[1][d]);
+#pragma unroll
+                for (int c3 = 0; c3 < 4; ++c3)
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) {
+                        const f32x4 wh = ws.take(g0 + kGemm1Groups + c3 * 4 + 2 * v), wm = ws.take(g0 + kGemm1Groups + c3 * 4 + 2 * v + 1);
+                        const u32x4 hh = u32x4{hs[0][4 * v], hs[0][4 * v + 1], hs[0][4 * v + 2], hs[0][4 * v + 3]};
+                        const u32x4 hm = u32x4{hs[1][4 * v], hs[1][4 * v + 1], hs[1][4 * v + 2], hs[1][4 * v + 3]};
+                        acc3[c3] = BF_MFMA16(wm, hm, acc3[c3]);
+                        acc3[c3] = BF_MFMA16(wm, hh, acc3[c3]);
+                        acc3[c3] = BF_MFMA16(wh, hm, acc3[c3]);
+                        acc3[c3] = BF_MFMA16(wh, hh, acc3[c3]);
+                    }
+            }
+        }
+    } else {
 #pragma unroll 1
     for (int it = 0; it < kC2Tiles / C2_UNROLL; ++it) {
 #pragma unroll
@@ -387,6 +449,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_eval_f32(const uint8_t* __restri
                     acc3[c3] = BF_MFMA(w.w, acc2[4 * tq + 3], acc3[c3]);
                 }
         }
+    }
     }
     if (DBG) {
 #pragma unroll
@@ -524,12 +587,16 @@ __global__ __launch_bounds__(256) void k_policy_scores(const float* __restrict__
 }  // namespace
 
 hipError_t launch_policy_features_f32(const uint8_t* d_mailbox, size_t n, const float* d_packed, float* d_x9,
-                                      hipStream_t stream) {
+                                      hipStream_t stream, bool split) {
     if (n == 0) return hipSuccess;
     const f32x4* ws = reinterpret_cast<const f32x4*>(d_packed + kOffStream);
     const unsigned blocks = (unsigned)((n + BPB - 1) / BPB);
-    hipLaunchKernelGGL(k_eval_f32<2>, dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, (unsigned)n, ws,
-                       d_packed + kOffBias, reinterpret_cast<const f32x4*>(d_packed + kOffHead), d_x9, nullptr);
+    if (split)
+        hipLaunchKernelGGL((k_eval_f32<2, true>), dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, (unsigned)n, ws,
+                           d_packed + kOffBias, reinterpret_cast<const f32x4*>(d_packed + kOffHead), d_x9, nullptr);
+    else
+        hipLaunchKernelGGL((k_eval_f32<2, false>), dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, (unsigned)n, ws,
+                           d_packed + kOffBias, reinterpret_cast<const f32x4*>(d_packed + kOffHead), d_x9, nullptr);
     return hipGetLastError();
 }
 
@@ -544,7 +611,7 @@ hipError_t launch_policy_scores(const float* d_x9, const float* d_logit_w, const
 }
 
 hipError_t launch_eval_f32(const uint8_t* d_mailbox, size_t n, const float* d_packed, float* d_scores,
-                           float* d_debug, hipStream_t stream) {
+                           float* d_debug, hipStream_t stream, bool split) {
     if (n == 0) return hipSuccess;
     const f32x4* ws = reinterpret_cast<const f32x4*>(d_packed + kOffStream);
     const float* bias = d_packed + kOffBias;
@@ -555,10 +622,18 @@ hipError_t launch_eval_f32(const uint8_t* d_mailbox, size_t n, const float* d_pa
 #else
     if (d_debug)
 #endif
-        hipLaunchKernelGGL(k_eval_f32<1>, dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, (unsigned)n, ws,
+    {
+        if (split)
+            hipLaunchKernelGGL((k_eval_f32<1, true>), dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, (unsigned)n, ws,
+                               bias, head, d_scores, d_debug);
+        else
+            hipLaunchKernelGGL((k_eval_f32<1, false>), dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, (unsigned)n, ws,
+                               bias, head, d_scores, d_debug);
+    } else if (split)
+        hipLaunchKernelGGL((k_eval_f32<0, true>), dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, (unsigned)n, ws,
                            bias, head, d_scores, d_debug);
     else
-        hipLaunchKernelGGL(k_eval_f32<0>, dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, (unsigned)n, ws,
+        hipLaunchKernelGGL((k_eval_f32<0, false>), dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, (unsigned)n, ws,
                            bias, head, d_scores, d_debug);
     return hipGetLastError();
 }

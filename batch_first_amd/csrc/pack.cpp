@@ -88,7 +88,7 @@ void split_bf16x3(float w, uint16_t out[3]) {
 
 }  // namespace
 
-void pack_weights(const float* blob, float* packed, bool policy) {
+void pack_weights(const float* blob, float* packed, bool policy, bool split) {
     const Canonical c = slice(blob, policy);
     std::memset(packed, 0, kPackedFloats * sizeof(float));
 
@@ -142,6 +142,39 @@ void pack_weights(const float* blob, float* packed, bool policy) {
         }
     }
     // 2. the 1x1 pair, per 32-channel tile of the 512-wide hidden layer
+    // split (BF_PRECISION_F32_SPLIT): the same 30 + 16 groups a tile, every group one A fragment of
+    // v_mfma_f32_32x32x16_bf16 (lane (row, h): 8 bf16, k = (h, j)), k-steps of 16 with the kernels as two bf16
+    // terms (hi, then mid = bf16(w - hi)) in consecutive groups.  236 -> 512: k-step s, element (h, j) = input channel
+    // 16 s + 2 j + h (x1 register 8 s + j of lane half h); channel slot 236 holds the folded shift (its B element is
+    // 1.0).  512 -> 128: k-step v, element (h, j) = hidden row rowmap(8 v + j, h) (accumulator register 8 v + j).
+    if (split) {
+        auto put_terms = [&](auto value_of) {   // value_of(lane, j) -> float; writes the hi group, then the mid group
+            for (int term = 0; term < 2; ++term) {
+                uint16_t* grp = reinterpret_cast<uint16_t*>(stream + (kstep >> 2) * kGroupFloats);
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const float v = value_of(lane, j);
+                        const uint16_t hi = bf16_rne(v);
+                        grp[lane * 8 + j] = term == 0 ? hi : bf16_rne(v - bf16_to_float(hi));
+                    }
+                kstep += 4;
+            }
+        };
+        for (int c2 = 0; c2 < kC2Tiles; ++c2) {
+            for (int s = 0; s < 15; ++s)
+                put_terms([&](int lane, int j) {
+                    const int h = lane >> 5, co = c2 * 32 + (lane & 31), ci = 16 * s + 2 * j + h;
+                    if (ci < kX1Channels) return c.tower_w[0][(size_t)ci * kC2 + co] * inv[1][co];
+                    return ci == kX1Channels ? bias[kBiasX2 + co] : 0.0f;
+                });
+            for (int c3 = 0; c3 < 4; ++c3)
+                for (int v = 0; v < 2; ++v)
+                    put_terms([&](int lane, int j) {
+                        const int h = lane >> 5, co = c3 * 32 + (lane & 31), ci = c2 * 32 + rowmap(8 * v + j, h);
+                        return c.tower_w[1][(size_t)ci * kC3 + co] * inv[2][co];
+                    });
+        }
+    } else
     for (int c2 = 0; c2 < kC2Tiles; ++c2) {
         for (int r = 0; r < 120; ++r) {  // 236 -> 512, k-step r = input channels 2r, 2r+1
             for (int lane = 0; lane < 64; ++lane) {
@@ -211,7 +244,7 @@ extern "C" int bf_pack_policy_weights(const float* h_weights, size_t n_floats, f
         return bf::fail(BF_E_ARG, "bf_pack_policy_weights: expected %zu weight floats, got %zu", bf::kPolicyWeightFloats, n_floats);
     if (n_packed != bf::kPackedFloats)
         return bf::fail(BF_E_ARG, "bf_pack_policy_weights: expected room for %zu packed floats, got %zu", bf::kPackedFloats, n_packed);
-    bf::pack_weights(h_weights, h_packed, true);
+    bf::pack_weights(h_weights, h_packed, true, false);
     return BF_OK;
 }
 
@@ -221,6 +254,6 @@ extern "C" int bf_pack_weights(const float* h_weights, size_t n_floats, float* h
         return bf::fail(BF_E_ARG, "bf_pack_weights: expected %zu weight floats, got %zu", bf::kWeightFloats, n_floats);
     if (n_packed != bf::kPackedFloats)
         return bf::fail(BF_E_ARG, "bf_pack_weights: expected room for %zu packed floats, got %zu", bf::kPackedFloats, n_packed);
-    bf::pack_weights(h_weights, h_packed, false);
+    bf::pack_weights(h_weights, h_packed, false, false);
     return BF_OK;
 }
