@@ -8,7 +8,7 @@ out=gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
 B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
-timeout -k 10 300 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > "$out/pytest_gpu.log" 2>&1 && tail -2 "$out/pytest_gpu.log"
+timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > "$out/pytest_gpu.log" 2>&1 && tail -2 "$out/pytest_gpu.log"
 timeout -k 10 240 python bench.py --steps 20 --warmup 3 > "$out/bench.json" 2> "$out/bench.err" && cat "$out/bench.json"
 timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > "$out/stats.log" 2>&1
 cp "$out"/stats/*/*_kernel_stats.csv "$out/kernel_stats.csv"

@@ -2,7 +2,7 @@
 per-launch HBM bytes should not carry another kernel's dirty lines: VERDICT round 2, "make the traffic figure
 reproducible").
 
-    python tools/kernel_only.py f32|bf16 [launches] [n]
+    python tools/kernel_only.py f32|f32s|bf16 [launches] [n]
 
 f32: k_eval_f32 on mailboxes made by ONE k_to_mailbox launch before a two-second pause; bf16: k_eval_t16<4>, which
 takes the records themselves (the kernel bench.py's timed step launches).  Prints the kernel's source hash, which
@@ -21,7 +21,8 @@ sys.path.insert(0, ROOT)
 
 
 def source_sha16(dtype):
-    files = {"f32": ["eval_f32.hip", "bf_layout.h", "pack.cpp"], "bf16": ["eval_t16.hip", "t16_common.h", "bf_layout_t16.h", "pack_t16.cpp"]}[dtype]
+    f32 = ["eval_f32.hip", "bf_layout.h", "pack.cpp"]
+    files = {"f32": f32, "f32s": f32, "bf16": ["eval_t16.hip", "t16_common.h", "bf_layout_t16.h", "pack_t16.cpp"]}[dtype]
     h = hashlib.sha256()
     for f in files:
         with open(os.path.join(ROOT, "batch_first_amd", "csrc", f), "rb") as fh:
@@ -43,12 +44,12 @@ def main():
     scores = torch.zeros(n, device="cuda")
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     mb = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
-    if dtype == "f32":
+    if dtype != "bf16":
         _lib.check(lib.bf_encode_mailbox_structs(ctx, recs.data_ptr(), recs.shape[1], n, mb.data_ptr(), st))
     torch.cuda.synchronize()
     time.sleep(2.0)   # whatever the set-up left dirty in the caches has been written back
     for _ in range(launches):
-        if dtype == "f32":
+        if dtype != "bf16":
             _lib.check(lib.bf_eval_mailbox(ctx, mb.data_ptr(), n, scores.data_ptr(), st))
         else:
             _lib.check(lib.bf_eval_structs(ctx, recs.data_ptr(), recs.shape[1], n, scores.data_ptr(), st))
