@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--no-policy", action="store_true")
     ap.add_argument("--cpu-material", action="store_true", help="no GPU: the reference's material-count fake (host-side ceiling)")
-    ap.add_argument("--threads", type=int, default=0, help="host threads of the search (0 = up to 8)")
+    ap.add_argument("--threads", type=int, default=0, help="host threads of the search (0 = the library default: cores - 4, at most 16)")
     ap.add_argument("--max-nodes", type=int, default=1 << 24, help="arena limit in nodes (0.8 KB each)")
     ap.add_argument("--fens", type=int, default=7, help="use the first N of the 7 test positions")
     ap.add_argument("--out", default=None)

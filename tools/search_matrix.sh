@@ -11,11 +11,14 @@ import json,sys; d=json.loads(sys.stdin.read()); print('$name', 'threads', d['ho
 run d4_b2048_t1  --depth 4 --batch 2048 --dtype bf16 --threads 1
 run d4_b2048_t12 --depth 4 --batch 2048 --dtype bf16 --threads 12
 run d4_b2048_t12_f32 --depth 4 --batch 2048 --dtype f32 --threads 12
+run d4_b2048_t12_f32s --depth 4 --batch 2048 --dtype f32s --threads 12
 run d5_b2048_t12 --depth 5 --batch 2048 --dtype bf16 --threads 12
 run d5_b8192_t1  --depth 5 --batch 8192 --dtype bf16 --threads 1
 run d5_b8192_t6 --depth 5 --batch 8192 --dtype bf16 --threads 6
 run d5_b8192_t12 --depth 5 --batch 8192 --dtype bf16 --threads 12
 run d5_b8192_t15 --depth 5 --batch 8192 --dtype bf16 --threads 15
+run d5_b8192_tdefault --depth 5 --batch 8192 --dtype bf16
+run d5_b8192_t24 --depth 5 --batch 8192 --dtype bf16 --threads 24
 run d5_b32768_t12 --depth 5 --batch 32768 --dtype bf16 --threads 12
 run d6_b32768_t12 --depth 6 --batch 32768 --dtype bf16 --threads 12 --fens 3
 run d5_b8192_t12_material --depth 5 --batch 8192 --threads 12 --cpu-material
