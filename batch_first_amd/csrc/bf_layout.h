@@ -60,9 +60,15 @@ constexpr int kConvTapGroups = 4;                          // 16 k-steps per tap
 constexpr int kConv4Groups = 4 * 9 * kConvTapGroups;       // 144
 constexpr int kConv59Groups = 5 * 9 * kConvTapGroups;      // 180
 constexpr int kStreamGroups = kInputGroups + kC2Tiles * kPerC2Groups + kConv4Groups + kConv59Groups;  // 1300
+// BF_PRECISION_F32_SPLIT: the same input and 1x1 sections (other contents, pack.cpp); a 3x3 chunk is 9 taps x 2 k-steps
+// of 16 channels x 3 bf16 terms of the kernels, one group (one v_mfma_f32_32x32x16_bf16 A fragment) each
+constexpr int kConvSplitChunkGroups = 9 * 2 * 3;           // 54
+constexpr int kStreamGroupsSplit = kInputGroups + kC2Tiles * kPerC2Groups + 10 * kConvSplitChunkGroups;  // 1516
 constexpr int kStreamChunk = 8;       // groups a workgroup walks between two barriers (eval_f32.hip)
 constexpr int kStreamPadGroups = 32;  // prefetch runs up to three chunks past the end
-constexpr size_t kStreamFloats = (size_t)(kStreamGroups + kStreamPadGroups) * kGroupFloats;
+// one image size for both precisions (the float32 stream leaves the tail of the region unused)
+constexpr size_t kStreamFloats = (size_t)(kStreamGroupsSplit + kStreamPadGroups) * kGroupFloats;
+static_assert(kStreamGroupsSplit >= kStreamGroups, "");
 
 // bias table: folded batch-norm shift per channel, layers back to back
 constexpr int kBiasX1 = 0, kBiasX2 = 236, kBiasX3 = 748, kBiasX4 = 876;  // x4..x9: 32 each

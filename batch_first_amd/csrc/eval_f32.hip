@@ -63,6 +63,14 @@ constexpr int THREADS = 64 * WAVES;
 constexpr int CHUNK = kStreamChunk;    // groups per lockstep chunk
 constexpr int SHARE = CHUNK / WAVES;   // groups each wave fetches per chunk
 constexpr int SLOTS = 3;
+// BF_PRECISION_F32_SPLIT consumes a group every two 32-cycle MFMAs (the float32 form: every four 64-cycle ones), so a
+// chunk lasts 512 cycles instead of 2048 and a fetch has two barriers = 0.4 us to land.  Measured with 3, 4 and 5
+// slots (profiles/r3/f32s/ab_slots.txt; 5 needs kStreamPadGroups = 48): 7.81, 7.80, 7.82 ms, no difference -- with
+// two workgroups per CU the other workgroup's wave covers the wait -- so the ring keeps three.
+#ifndef BF_F32_SPLIT_SLOTS
+#define BF_F32_SPLIT_SLOTS 3
+#endif
+constexpr int SPLIT_SLOTS = BF_F32_SPLIT_SLOTS;
 #ifndef BF_F32_LA
 #define BF_F32_LA 3
 #endif
@@ -76,7 +84,7 @@ static_assert(CHUNK % WAVES == 0, "every wave fetches whole groups");
 static_assert(kInputGroups % CHUNK == 0, "the tile loop must start on a chunk boundary");
 static_assert((kPerC2Groups * C2_UNROLL) % CHUNK == 0, "loop body must be whole chunks");
 static_assert(kC2Tiles % C2_UNROLL == 0, "");
-static_assert(kStreamPadGroups >= 3 * CHUNK + LA, "prefetch overrun must stay inside the image");
+static_assert(kStreamPadGroups >= SPLIT_SLOTS * CHUNK + LA && kStreamPadGroups >= 3 * CHUNK + LA, "prefetch overrun must stay inside the image");
 
 constexpr int MB_W = 22;     // mailbox padded by 7 squares (largest dilation) on every side
 constexpr int MB_BYTES = 496;
@@ -86,17 +94,28 @@ constexpr int XBUF_FLOATS = 32 * XP_PLANE;
 constexpr int RED_STRIDE = 17;
 static_assert(128 * RED_STRIDE <= XBUF_FLOATS, "the head's reduction scratch aliases one activation buffer");
 
-struct Lds {
-    f32x4 wring[SLOTS][CHUNK][64];       // shared A-fragment ring
-    float xbuf[BPB][2][XBUF_FLOATS];     // per board: two alternating zero-haloed activation buffers
+// SPLIT: the 3x3 layers' activations as THREE bf16 terms (24 significant bits), one plane per term,
+// [10x10 positions][32 channels] bf16 = 64 bytes a position: 19.2 KB a board, ONE buffer (two would leave room for one
+// workgroup per CU only), so a chunk's writes wait for the readers of the chunk before it at a second barrier.
+constexpr int XS_POS_BYTES = 64;
+constexpr int XS_PLANE_BYTES = XP_PLANE * XS_POS_BYTES;   // 6 400
+constexpr int XS_FLOATS = 3 * XS_PLANE_BYTES / 4;         // 4 800
+static_assert(128 * RED_STRIDE <= XS_FLOATS, "the head's reduction scratch aliases the activation planes");
+
+template <bool SPLIT>
+struct LdsT {
+    f32x4 wring[SPLIT ? SPLIT_SLOTS : SLOTS][CHUNK][64];   // shared A-fragment ring
+    // per board: two alternating zero-haloed activation buffers (float32), or the three term planes
+    float xbuf[BPB][SPLIT ? 1 : 2][SPLIT ? XS_FLOATS : XBUF_FLOATS];
     unsigned char mb[BPB][MB_BYTES];     // per board: padded code mailbox
 #ifdef BF_ABL_LDSPAD
     char pad[20000];
 #endif
 };
 
-// Lockstep walk over the A-fragment stream through the LDS ring.
-struct WStream {
+// Lockstep walk over the A-fragment stream through the LDS ring of S slots.
+template <int S>
+struct WStreamT {
     const f32x4* src;      // this lane's element of this wave's share of the chunk to fetch next
     f32x4* ring;           // &lds.wring[0][0][lane]
     unsigned lds_share;    // LDS byte address of &lds.wring[0][wave * SHARE][0]: where this wave's share of slot 0 lands
@@ -135,29 +154,29 @@ struct WStream {
         ring = ring_base + lane;
         lds_share = (unsigned)(uintptr_t)(lds_ptr)(ring_base + wave * SHARE * 64);
         src = stream + wave * SHARE * 64 + lane;
-        fetch_into(0);                  // chunk 0
-        fetch_into(CHUNK * 64);         // chunk 1
-        rd = (SLOTS - 1) * CHUNK * 64;  // start()'s next_chunk() moves to slot 0
+#pragma unroll
+        for (int k = 0; k < S - 1; ++k) fetch_into(k * CHUNK * 64);   // chunks 0 .. S-2
+        rd = (S - 1) * CHUNK * 64;  // start()'s next_chunk() moves to slot 0
     }
     // Chunk boundary (a fixed place in the code, the same for all waves of the block): after the
     // barrier every wave's share of chunk k is in LDS and nobody reads chunk k-1 any more, so its
-    // slot takes chunk k+2.
+    // slot takes chunk k+S-1.
     __device__ __forceinline__ void next_chunk() {
         const int free_slot = rd;       // chunk k-1
-        rd = (rd == (SLOTS - 1) * CHUNK * 64) ? 0 : rd + CHUNK * 64;
+        rd = (rd == (S - 1) * CHUNK * 64) ? 0 : rd + CHUNK * 64;
         // keep the barrier behind the previous group's MFMAs: they cover the latency of the LDS read
         // just issued, which the barrier's lgkmcnt(0) would otherwise sit out with the pipe idle
         __builtin_amdgcn_sched_barrier(0);
 #ifdef BF_F32_FULLWAIT
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #else
-        // Only chunk k has to have landed here: this wave's share of it was fetched two barriers ago, the share
-        // of chunk k+1 (one barrier ago, the SHARE youngest loads) may still be in flight.  __syncthreads() would
+        // Only chunk k has to have landed here: this wave's share of it was fetched S-1 barriers ago, the shares
+        // of chunks k+1 .. k+S-2 (the (S-2) SHARE youngest loads) may still be in flight.  __syncthreads() would
         // wait for vmcnt(0), i.e. give the fetch one chunk (2048 cycles) to land instead of two.
 #ifdef BF_ABL_NOBAR   // timing ablation (races): waves do not wait for each other
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SHARE) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * SHARE) : "memory");
 #else
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(SHARE) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((S - 2) * SHARE) : "memory");
 #endif
 #endif
         __builtin_amdgcn_sched_barrier(0);
@@ -200,7 +219,7 @@ __device__ __forceinline__ float relu(float x) {
 
 // Stage 1, one input conv.  reference: ann_creation_helper.py:211-236 (SAME padding:
 // (k-1)*d in total, floor(/2) before).
-template <int I>
+template <int I, class WStream>
 __device__ __forceinline__ void input_conv(WStream& ws, const unsigned char* mb_center, int hl,
                                            const float* __restrict__ bias, float (&x1)[kX1Regs]) {
     constexpr InputConv cv = kInputConvs[I];
@@ -253,6 +272,7 @@ __device__ __forceinline__ void input_conv(WStream& ws, const unsigned char* mb_
 // One 3x3 SAME conv over a 32-channel chunk staged in a zero-haloed LDS plane:
 // acc[co][sq] += sum_tap sum_ci W[tap][ci][co] * x[ci][sq + tap offset].
 // g0 must be a compile-time constant at every (inlined) call site.
+template <class WStream>
 __device__ __forceinline__ void conv3x3_chunk(WStream& ws, int g0, const float* xb_lane, f32x16& acc) {
     // B operands are read from LDS one group (4 k-steps) ahead of the MFMAs that use them.
     auto load_b = [&](int idx, float (&b)[4]) {
@@ -284,15 +304,64 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
     const float rb = b - __builtin_bit_cast(float, hi & 0xFFFF0000u);
     mid = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{ra, rb}, bf16x2));
 }
+// Three terms: hi + mid + lo carries 24 significant bits (all of a float32 unless it is subnormal).
+__device__ __forceinline__ void split3(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+    const float ra = a - __builtin_bit_cast(float, hi << 16);
+    const float rb = b - __builtin_bit_cast(float, hi & 0xFFFF0000u);
+    mid = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{ra, rb}, bf16x2));
+    const float sa = ra - __builtin_bit_cast(float, mid << 16);
+    const float sb = rb - __builtin_bit_cast(float, mid & 0xFFFF0000u);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{sa, sb}, bf16x2));
+}
 #define BF_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
+
+// SPLIT form of conv3x3_chunk: kernels and activations as three bf16 terms each, the six products whose weight is
+// at least 2^-16 of the leading one (hi hi, hi mid, mid hi, mid mid, hi lo, lo hi), small ones first, on
+// v_mfma_f32_32x32x16_bf16: 108 32-cycle MFMAs a chunk instead of 144 64-cycle ones, 54 stream groups (pack.cpp).
+// Plane layout: position p (10 x 10, zero halo) is 64 bytes = four 16-byte chunks; chunk c = 2 s + h holds the eight
+// channels of k-step s, lane half h, i.e. accumulator registers 8 h .. 8 h + 7 of the writing lane half s, and sits at
+// chunk (c + padded rank) & 3 of its position: the four lane groups of a ds_read_b128 (MI355X_MICROARCH.md, LDS) hold
+// one run of four files from each of four consecutive ranks, so every shifted read is conflict-free.
+// xa[j]: this lane's byte address of chunk (j + h + rank) & 3 of the position one row and one column back.
+template <class WStream>
+__device__ __forceinline__ void conv3x3_chunk_split(WStream& ws, int g0, const char* const (&xa)[4], f32x16& acc) {
+    auto load_b = [&](int idx, u32x4 (&b)[3]) {
+        const int tap = idx >> 1, s = idx & 1, tr = tap / 3, tf = tap % 3;
+        const char* p = xa[(2 * s + tr) & 3] + (tr * XP_W + tf) * XS_POS_BYTES;
+#pragma unroll
+        for (int term = 0; term < 3; ++term) b[term] = *reinterpret_cast<const u32x4*>(p + term * XS_PLANE_BYTES);
+    };
+    u32x4 b[2][3];
+    load_b(0, b[0]);
+#pragma unroll
+    for (int idx = 0; idx < 18; ++idx) {
+        if (idx + 1 < 18) load_b(idx + 1, b[(idx + 1) & 1]);
+        const f32x4 wh = ws.take(g0 + 3 * idx), wm = ws.take(g0 + 3 * idx + 1), wl = ws.take(g0 + 3 * idx + 2);
+        const u32x4 &xh = b[idx & 1][0], &xm = b[idx & 1][1], &xl = b[idx & 1][2];
+#ifndef BF_ABL_5PROD   // timing ablation (wrong scores)
+        acc = BF_MFMA16(wl, xh, acc);
+#endif
+#ifndef BF_ABL_4PROD
+        acc = BF_MFMA16(wh, xl, acc);
+#endif
+        acc = BF_MFMA16(wm, xm, acc);
+        acc = BF_MFMA16(wm, xh, acc);
+        acc = BF_MFMA16(wh, xm, acc);
+        acc = BF_MFMA16(wh, xh, acc);
+    }
+}
 
 // MODE 0: scores; 1: scores + every intermediate activation (debug); 2: features -- x9, the
 // activations after the six 3x3 layers, as float32 [board][32][64] into `scores`, no head (the
 // move-scoring network, whose 1x1 logit layer is applied per requested move by k_policy_scores).
 // SPLIT (BF_PRECISION_F32_SPLIT, include/batchfirst.h): the 1x1 pair, 68 % of the network's FLOPs, runs on
 // v_mfma_f32_32x32x16_bf16 with both operands as TWO bf16 terms (16 significant bits) and all four products,
-// float32 sums: 92 32-cycle MFMAs a hidden tile instead of 183 64-cycle ones.  Everything else is this kernel
-// unchanged.  Same stream shape (30 + 16 groups a hidden tile), other contents: pack.cpp.
+// float32 sums: 92 32-cycle MFMAs a hidden tile instead of 183 64-cycle ones (same stream shape, 30 + 16 groups a
+// hidden tile, other contents: pack.cpp); and the six 3x3 layers with both operands as THREE bf16 terms
+// (conv3x3_chunk_split).  Stage 1 and the head are this kernel unchanged.
 template <int MODE, bool SPLIT>
 __global__ __launch_bounds__(THREADS, 2) void k_eval_f32(const uint8_t* __restrict__ mailbox, unsigned n_boards,
                                                           const f32x4* __restrict__ wstream,
@@ -300,7 +369,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_eval_f32(const uint8_t* __restri
                                                           const f32x4* __restrict__ headw,
                                                           float* __restrict__ scores, float* __restrict__ dbg) {
     constexpr bool DBG = MODE == 1;
-    __shared__ __attribute__((aligned(16))) Lds lds;
+    __shared__ __attribute__((aligned(16))) LdsT<SPLIT> lds;
     const int tid = threadIdx.x;
     const int lane = tid & 63, hl = lane >> 5, ln = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -316,14 +385,14 @@ __global__ __launch_bounds__(THREADS, 2) void k_eval_f32(const uint8_t* __restri
     long long stamps[12];
 #endif
     BF_STAMP(0);
-    WStream ws;
+    WStreamT<SPLIT ? SPLIT_SLOTS : SLOTS> ws;
     ws.prime(wstream, &lds.wring[0][0][0], lane, wave);
 
     // ---- LDS set-up: empty mailbox (0xFF everywhere), zero activation planes ------------
     if (btid < MB_BYTES / 4) reinterpret_cast<unsigned*>(lds.mb[bib])[btid] = 0xFFFFFFFFu;
     {
         f32x4* z = reinterpret_cast<f32x4*>(&lds.xbuf[bib][0][0]);
-        for (int i = btid; i < 2 * XBUF_FLOATS / 4; i += 128) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = btid; i < (int)(sizeof(lds.xbuf[0]) / 16); i += 128) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
     if (btid < 64) {
@@ -462,11 +531,63 @@ __global__ __launch_bounds__(THREADS, 2) void k_eval_f32(const uint8_t* __restri
     BF_STAMP(3);
     // ---- stages 3 and 4: the six 3x3 layers through LDS -----------------------------------
     constexpr int GC = kInputGroups;  // static chunk phase after the loop (the loop preserves it)
-    const int wpos = (rank + 1) * XP_W + file + 1;           // where this lane's square lives
-    const int rpos = hl * XP_PLANE + rank * XP_W + file;     // one row and column back, plane hl
     f32x16 acc;
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc[t] = pick(hl, bias[kBiasX4 + rowmap(t, 0)], bias[kBiasX4 + rowmap(t, 1)]);
+    if (SPLIT) {
+        char* planes = reinterpret_cast<char*>(&lds.xbuf[bib][0][0]);
+        const char* xa[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xa[j] = planes + (rank * XP_W + file) * XS_POS_BYTES + ((j + hl + rank) & 3) * 16;
+        // this lane's square: registers 8 cq .. 8 cq + 7 are chunk 2 hl + cq, padded rank = rank + 1
+        char* wa[2];
+#pragma unroll
+        for (int cq = 0; cq < 2; ++cq)
+            wa[cq] = planes + ((rank + 1) * XP_W + file + 1) * XS_POS_BYTES + ((2 * hl + cq + rank + 1) & 3) * 16;
+        auto store_planes = [&](const f32x16& v) {   // ReLU, three terms, 2 x 3 16-byte stores
+#pragma unroll
+            for (int cq = 0; cq < 2; ++cq) {
+                u32x4 th, tm, tl;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    unsigned h_, m_, l_;
+                    split3(relu(v[8 * cq + 2 * d]), relu(v[8 * cq + 2 * d + 1]), h_, m_, l_);
+                    th[d] = h_; tm[d] = m_; tl[d] = l_;
+                }
+                *reinterpret_cast<u32x4*>(wa[cq]) = th;
+                *reinterpret_cast<u32x4*>(wa[cq] + XS_PLANE_BYTES) = tm;
+                *reinterpret_cast<u32x4*>(wa[cq] + 2 * XS_PLANE_BYTES) = tl;
+            }
+        };
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#ifndef BF_ABL_NOBAR2   // timing ablation (races)
+            if (q > 0) __syncthreads();   // the other half's reads of the chunk before this one are done
+#endif
+            store_planes(acc3[q]);
+            __syncthreads();
+            conv3x3_chunk_split(ws, GC + q * kConvSplitChunkGroups, xa, acc);
+        }
+        BF_STAMP(4);
+#pragma unroll
+        for (int layer = 0; layer < 5; ++layer) {
+            if (DBG) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) dbg_board[64 * (236 + 128 + 32 * layer) + rowmap(t, hl) * 64 + sq] = relu(acc[t]);
+            }
+#ifndef BF_ABL_NOBAR2
+            __syncthreads();
+#endif
+            store_planes(acc);
+            __syncthreads();
+            const float* bl = bias + kBiasX4 + 32 * (layer + 1);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[t] = pick(hl, bl[rowmap(t, 0)], bl[rowmap(t, 1)]);
+            conv3x3_chunk_split(ws, GC + (4 + layer) * kConvSplitChunkGroups, xa, acc);
+        }
+    } else {
+    const int wpos = (rank + 1) * XP_W + file + 1;           // where this lane's square lives
+    const int rpos = hl * XP_PLANE + rank * XP_W + file;     // one row and column back, plane hl
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         float* xb = lds.xbuf[bib][q & 1];
@@ -490,6 +611,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_eval_f32(const uint8_t* __restri
 #pragma unroll
         for (int t = 0; t < 16; ++t) acc[t] = pick(hl, bl[rowmap(t, 0)], bl[rowmap(t, 1)]);
         conv3x3_chunk(ws, GC + 144 + layer * 36, xb + rpos, acc);
+    }
     }
 
     BF_STAMP(5);
@@ -529,7 +651,9 @@ __global__ __launch_bounds__(THREADS, 2) void k_eval_f32(const uint8_t* __restri
     }
     // The last 3x3 layer read buffer 0 (layer 4); buffer 1 was last read one barrier earlier,
     // so its space can hold the reduction scratch (this block is done with the planes).
-    float* red = lds.xbuf[bib][1];
+    // (SPLIT has one buffer: a barrier first, so that the other half's reads of the last layer are done.)
+    if (SPLIT) __syncthreads();
+    float* red = lds.xbuf[bib][SPLIT ? 0 : 1];
 #pragma unroll
     for (int co = 0; co < 16; ++co) red[btid * RED_STRIDE + co] = part[co];
     __syncthreads();
@@ -589,6 +713,9 @@ __global__ __launch_bounds__(256) void k_policy_scores(const float* __restrict__
 hipError_t launch_policy_features_f32(const uint8_t* d_mailbox, size_t n, const float* d_packed, float* d_x9,
                                       hipStream_t stream, bool split) {
     if (n == 0) return hipSuccess;
+#ifdef BF_ONLY_SPLIT_SCORES   // experiment builds (tools/build_variant.sh): k_eval_f32<0, true> alone is instantiated
+    return hipErrorNotSupported;
+#else
     const f32x4* ws = reinterpret_cast<const f32x4*>(d_packed + kOffStream);
     const unsigned blocks = (unsigned)((n + BPB - 1) / BPB);
     if (split)
@@ -598,6 +725,7 @@ hipError_t launch_policy_features_f32(const uint8_t* d_mailbox, size_t n, const 
         hipLaunchKernelGGL((k_eval_f32<2, false>), dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, (unsigned)n, ws,
                            d_packed + kOffBias, reinterpret_cast<const f32x4*>(d_packed + kOffHead), d_x9, nullptr);
     return hipGetLastError();
+#endif
 }
 
 hipError_t launch_policy_scores(const float* d_x9, const float* d_logit_w, const unsigned* d_board_index,
@@ -617,6 +745,12 @@ hipError_t launch_eval_f32(const uint8_t* d_mailbox, size_t n, const float* d_pa
     const float* bias = d_packed + kOffBias;
     const f32x4* head = reinterpret_cast<const f32x4*>(d_packed + kOffHead);
     const unsigned blocks = (unsigned)((n + BPB - 1) / BPB);
+#ifdef BF_ONLY_SPLIT_SCORES
+    if (!split) return hipErrorNotSupported;
+    hipLaunchKernelGGL((k_eval_f32<0, true>), dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, (unsigned)n, ws, bias, head,
+                       d_scores, d_debug);
+    return hipGetLastError();
+#else
 #ifdef BF_STAMPS
     if (false)
 #else
@@ -636,6 +770,7 @@ hipError_t launch_eval_f32(const uint8_t* d_mailbox, size_t n, const float* d_pa
         hipLaunchKernelGGL((k_eval_f32<0, false>), dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, (unsigned)n, ws,
                            bias, head, d_scores, d_debug);
     return hipGetLastError();
+#endif
 }
 
 }  // namespace bf

@@ -210,8 +210,31 @@ void pack_weights(const float* blob, float* packed, bool policy, bool split) {
                 ++kstep;
             }
     };
-    for (int q = 0; q < 4; ++q) conv3(c.tower_w[2], 128, q, inv[3]);
-    for (int l = 0; l < 5; ++l) conv3(c.tower_w[3 + l], 32, 0, inv[4 + l]);
+    // split: per tap two k-steps of 16 input channels, the kernels as THREE bf16 terms (hi, mid, lo: hi + mid + lo == w
+    // exactly) in consecutive groups.  k-step s, element (h, j) = input channel rowmap(8 h + j, s) of the chunk: the
+    // channel that accumulator register 8 h + j of lane half s held in the layer before (eval_f32.hip, plane layout).
+    auto conv3_split = [&](const float* w, int cin, int chunk, const std::vector<float>& scale) {
+        for (int tap = 0; tap < 9; ++tap)
+            for (int s = 0; s < 2; ++s)
+                for (int term = 0; term < 3; ++term) {
+                    uint16_t* grp = reinterpret_cast<uint16_t*>(stream + (kstep >> 2) * kGroupFloats);
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int h = lane >> 5, co = lane & 31, ci = chunk * 32 + rowmap(8 * h + j, s);
+                            uint16_t parts[3];
+                            split_bf16x3(w[((size_t)tap * cin + ci) * 32 + co] * scale[co], parts);
+                            grp[lane * 8 + j] = parts[term];
+                        }
+                    kstep += 4;
+                }
+    };
+    if (split) {
+        for (int q = 0; q < 4; ++q) conv3_split(c.tower_w[2], 128, q, inv[3]);
+        for (int l = 0; l < 5; ++l) conv3_split(c.tower_w[3 + l], 32, 0, inv[4 + l]);
+    } else {
+        for (int q = 0; q < 4; ++q) conv3(c.tower_w[2], 128, q, inv[3]);
+        for (int l = 0; l < 5; ++l) conv3(c.tower_w[3 + l], 32, 0, inv[4 + l]);
+    }
 
     // ---- head: 8x8 valid conv as a 2048 -> 16 dense layer --------------------------
     float* head = packed + kOffHead;

@@ -241,26 +241,32 @@ def main():
                               "traffic": o_traffic, "traffic_source": o_src, "traffic_matches_sources": o_match,
                               "flops_per_board": spec.FLOPS_PER_BOARD}}
         o_ctx.close()
-    # BF_PRECISION_F32_SPLIT beside them (round 3): the fp32 kernel whose 1x1 pair runs as four two-term bf16
-    # products.  It mixes two matrix pipes, so it carries no fraction of either peak for the whole kernel: the block
-    # gives boards/s, the kernel time, and the bf16 work the pair EXECUTES (4 products, K padded to 240 and 512)
-    # over the whole kernel time against the bf16 peak
+    # BF_PRECISION_F32_SPLIT beside them (round 3): the fp32 kernel's structure with the 1x1 pair and the 3x3 layers
+    # as sums of bf16 x bf16 products.  No fraction of the fp32 peak (it executes no fp32 MFMA); the block gives
+    # boards/s, the kernel time beside k_eval_f32's, and the bf16 MFMA work the kernel EXECUTES per board (2 waves x
+    # (240 + 16 x 92 + 10 x 108) v_mfma_f32_32x32x16_bf16 of 32 768 FLOP: 5.2 x the algorithmic FLOPs, that is the
+    # price of the terms) against the bf16 peak
     split = None
     if not bf16:
         s_elapsed, s_kernel_ms, _, s_ctx = measure("f32s")
-        pair_flops = 4 * 2 * 64 * (240 * 512 + 512 * 128)
-        s_tflops = pair_flops * n_kernel / (s_kernel_ms * 1e-3) / 1e12
+        mfma_per_board = 2 * (240 + 16 * 92 + 10 * 108)
+        executed = mfma_per_board * 32768
+        s_tflops = executed * n_kernel / (s_kernel_ms * 1e-3) / 1e12
         split = {"value": total_boards * args.steps / s_elapsed, "unit": "boards/s", "steps": args.steps, "warmup": args.warmup,
                  "ms_per_step": 1e3 * s_elapsed / args.steps, "dtype": "f32s",
-                 "config": {"workload": "BF_PRECISION_F32_SPLIT on the headline's records and batch: fp32 everywhere but the "
-                                        "236->512->128 pair, which is hi+mid bf16 x hi+mid bf16 with fp32 sums "
-                                        "(scores within the fp32 kernel's 1e-4 bound, tests/test_gpu_parity.py)"},
-                 "kernel": "k_eval_f32<.., SPLIT>", "kernel_ms": s_kernel_ms, "kernel_ms_f32": kernel_ms,
+                 "config": {"workload": "BF_PRECISION_F32_SPLIT on the headline's records and batch: 236->512->128 pair as "
+                                        "(hi+mid) x (hi+mid) bf16, six 3x3 layers as (hi+mid+lo) x (hi+mid+lo) bf16 (six "
+                                        "products), fp32 sums, stage 1 and head as the fp32 kernel (scores within the fp32 "
+                                        "kernel's 1e-4 bound, tests/test_gpu_parity.py)"},
+                 "kernel": "k_eval_f32<0, SPLIT>", "kernel_ms": s_kernel_ms, "kernel_ms_f32": kernel_ms,
                  "speedup_over_f32_kernel": kernel_ms / s_kernel_ms,
-                 "executed_bf16": {"flops_per_board": pair_flops, "achieved": s_tflops, "peak": PEAK_BF16_MFMA_TFLOPS,
-                                   "unit": "TFLOP/s", "share_of_bf16_peak": s_tflops / PEAK_BF16_MFMA_TFLOPS,
-                                   "note": "the pair's executed bf16 work over the WHOLE kernel time; the rest of the kernel "
-                                           "is fp32 MFMA, so this is no roofline fraction of the kernel"}}
+                 "executed_bf16": {"mfma_per_board": mfma_per_board, "flops_per_board": executed, "achieved": s_tflops,
+                                   "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                   "share_of_bf16_peak": s_tflops / PEAK_BF16_MFMA_TFLOPS,
+                                   "algorithmic_flops_per_board": spec.FLOPS_PER_BOARD,
+                                   "note": "executed bf16 MFMA work (all terms and products), not algorithmic FLOPs: "
+                                           "a utilisation figure for this kernel, not comparable with the roofline "
+                                           "fractions above"}}
         s_ctx.close()
     if shard:
         recs = recs[:65536].contiguous()

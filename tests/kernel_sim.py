@@ -11,7 +11,7 @@ INPUT_CONVS = [(3, 1, 1, 64, 0, 2), (3, 2, 2, 32, 64, 1), (3, 3, 3, 20, 96, 1), 
                (3, 5, 5, 18, 136, 1), (3, 6, 6, 18, 154, 1), (3, 7, 7, 16, 172, 1), (2, 2, 4, 24, 188, 1),
                (2, 4, 2, 24, 212, 1)]
 STREAM_GROUPS = 1300
-STREAM_PAD = 32
+STREAM_REGION = 1516 + 32   # groups the image reserves: the split precision's stream (bf_layout.h: kStreamGroupsSplit) + padding
 BIAS_FLOATS = 1104
 B_X1, B_X2, B_X3, B_X4, B_X10, B_LOGIT = 0, 236, 748, 876, 1068, 1084
 
@@ -52,7 +52,7 @@ def mfma(a, b, acc):
 
 class Stream:
     def __init__(self, packed):
-        self.data = packed[:(STREAM_GROUPS + STREAM_PAD) * 256].reshape(-1, 64, 4)
+        self.data = packed[:STREAM_REGION * 256].reshape(-1, 64, 4)
         self.kstep = 0
 
     def next_group_bf16(self):
@@ -75,8 +75,8 @@ class Stream:
 def eval_board(packed, mailbox64):
     """mailbox64: uint8[64] codes (15 = empty) in the mover's frame.  Returns (score, intermediates)."""
     packed = np.asarray(packed, np.float32)
-    bias = packed[(STREAM_GROUPS + STREAM_PAD) * 256:][:BIAS_FLOATS].astype(np.float64)
-    head = packed[(STREAM_GROUPS + STREAM_PAD) * 256 + BIAS_FLOATS:].reshape(2, 64, 64, 4).astype(np.float64)
+    bias = packed[STREAM_REGION * 256:][:BIAS_FLOATS].astype(np.float64)
+    head = packed[STREAM_REGION * 256 + BIAS_FLOATS:].reshape(2, 64, 64, 4).astype(np.float64)
     mb = np.full((22, 22), 255, np.int64)
     mb[7:15, 7:15] = np.where(mailbox64 == 15, 255, mailbox64).reshape(8, 8)
 
