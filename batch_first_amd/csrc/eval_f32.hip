@@ -746,8 +746,11 @@ hipError_t launch_eval_f32(const uint8_t* d_mailbox, size_t n, const float* d_pa
     const f32x4* head = reinterpret_cast<const f32x4*>(d_packed + kOffHead);
     const unsigned blocks = (unsigned)((n + BPB - 1) / BPB);
 #ifdef BF_ONLY_SPLIT_SCORES
-    if (!split) return hipErrorNotSupported;
-    hipLaunchKernelGGL((k_eval_f32<0, true>), dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, (unsigned)n, ws, bias, head,
+#ifndef BF_ONLY_SPLIT_VALUE
+#define BF_ONLY_SPLIT_VALUE true
+#endif
+    if (split != BF_ONLY_SPLIT_VALUE) return hipErrorNotSupported;
+    hipLaunchKernelGGL((k_eval_f32<0, BF_ONLY_SPLIT_VALUE>), dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, (unsigned)n, ws, bias, head,
                        d_scores, d_debug);
     return hipGetLastError();
 #else

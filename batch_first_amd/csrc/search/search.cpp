@@ -105,6 +105,20 @@ struct Node {
     float move_scores[kMaxMoves];
 };
 
+// What the tree update reads and writes of an ARENA node, 32 bytes instead of lines scattered over 0.8 KB: the walk
+// from a finished child to the root touches these fields only, and in the node itself they share cache lines with
+// the move list that the expanding threads write (next_move_index, move_scores), so every hop was a line fetched
+// from another core.  The arena node's own best_value / terminated / children_left are not maintained after it
+// enters the arena; children in the batch's `fresh` block use their Node fields as before.
+struct Hot {
+    u64 hash;
+    int parent;
+    float separator, best_value;
+    uint8_t depth, terminated, children_left;
+    Move prev_move;
+};
+static_assert(sizeof(Hot) == 32, "two tree-state entries a cache line");
+
 // The node arena: fixed blocks, so that growing never copies or zeroes what is there (a std::vector of 800-byte
 // nodes spent a sixth of the search re-allocating), and an index stays valid for the whole search.
 class Arena {
@@ -175,6 +189,22 @@ struct bfs_search {
         void operator()(uint32_t* p) const { std::free(p); }
     };
     std::unique_ptr<uint32_t[], FreeDeleter> up;
+    struct FreeHot {
+        void operator()(Hot* p) const { std::free(p); }
+    };
+    std::unique_ptr<Hot[], FreeHot> hot;   // tree state of the arena's nodes (struct Hot); allocated like `up`
+    void enter_tree(int id, const Node& n) {   // a node takes its place in the arena
+        Hot& h = hot[id];
+        h.hash = n.b.hash;
+        h.parent = n.parent;
+        h.separator = n.separator;
+        h.best_value = n.best_value;
+        h.depth = n.depth;
+        h.terminated = n.terminated;
+        h.children_left = n.children_left;
+        h.prev_move = n.prev_move;
+        up[id] = (uint32_t)(n.parent + 1) | (n.terminated ? kDead : 0u);
+    }
     static constexpr uint32_t kDead = 0x80000000u;
     bfs_stats stats{};
     std::string error;
@@ -210,7 +240,15 @@ struct bfs_search {
     // ---- transposition table (transposition_table.py) ------------------------------------
     TTEntry& entry(u64 h) { return tt[h & tt_mask]; }
 
-    void tt_add(const Node& n, Move following) {  // add_board_and_move_to_tt, :86-133
+    struct TreeNodeView {   // tt_add's view of an arena node (struct Hot)
+        struct {
+            u64 hash;
+        } b;
+        float best_value, separator;
+        uint8_t depth;
+    };
+    void tt_add(const Hot& h, Move following) { tt_add(TreeNodeView{{h.hash}, h.best_value, h.separator, h.depth}, following); }
+    void tt_add(const TreeNodeView& n, Move following) {  // add_board_and_move_to_tt, :86-133
         TTEntry& e = entry(n.b.hash);
         const bool lower_side = n.best_value >= n.separator;
         if (e.depth != kNoEntry) {
@@ -280,7 +318,7 @@ struct bfs_search {
     // ---- tree updates (numba_negamax_zero_window.py:399-419) --------------------------------
     void update_from_value(int id, float value, Move following, bool new_termination = true) {
         while (id >= 0) {
-            Node& n = nodes[id];
+            Hot& n = hot[id];
             if (n.terminated) {
                 if (!(value > n.best_value)) return;
                 n.best_value = value;
@@ -608,10 +646,11 @@ struct bfs_search {
         size_t e = 0;
         for (size_t j = 0; j < n; ++j) {
             Node& c = fresh[j];
-            if (j + 8 < n) {   // the table lines this loop will touch a few children from now: the child's and its parent's
+            if (j + 16 < n) __builtin_prefetch(&hot[fresh[j + 16].parent], 1);   // the parent's tree state, then ...
+            if (j + 8 < n) {   // ... the table lines this loop will touch a few children from now: the child's and its parent's
                 const Node& ahead = fresh[j + 8];
                 __builtin_prefetch(&entry(ahead.b.hash), 1);
-                __builtin_prefetch(&entry(nodes[ahead.parent].b.hash), 1);
+                __builtin_prefetch(&entry(hot[ahead.parent].hash), 1);
             }
             if (e < to_eval.size() && to_eval[e] == (int)j) {
                 const float s = eval_scores[e++] - cfg.eval_zero_shift;
@@ -775,7 +814,7 @@ struct bfs_search {
                         __builtin_prefetch(p + off, 1);
                 }
                 std::memcpy(static_cast<void*>(&dst), static_cast<const void*>(&src), offsetof(Node, moves));
-                up[base + i] = (uint32_t)(src.parent + 1);   // open children are not terminated
+                enter_tree((int)(base + i), src);   // (open children are not terminated)
                 std::memcpy(dst.moves, src.moves, src.n_moves * sizeof(Move));
                 std::memcpy(dst.move_scores, src.move_scores, src.n_moves * sizeof(float));
             }
@@ -808,7 +847,10 @@ struct bfs_search {
         r.next_move_index = kNoMoreMoves;
         r.children_left = 0;
         r.prev_move = kNoMove;
-        up[0] = 0;
+        struct RootEnters {   // however this function is left, the root's tree state is what the node holds by then
+            bfs_search* s;
+            ~RootEnters() { s->enter_tree(0, s->nodes[0]); }
+        } root_enters{this};
         if (depth == 0) {
             // the reference never searches to depth 0; give the evaluation so callers get a value
             if (settle(r)) {
@@ -839,13 +881,13 @@ struct bfs_search {
     int zero_window(const Board& start, int depth, float separator, float* value) {
         const double t0 = now();
         if (int rc = make_root(start, depth, separator)) return rc;
-        if (!nodes[0].terminated) {
+        if (!hot[0].terminated) {
             std::vector<int> batch{0}, to_insert;
             std::vector<float> scores;
             stats.nodes_out += 1;
             while (!batch.empty()) {
                 if (int rc = iterate(batch, &to_insert, &scores)) return rc;
-                if (nodes[0].terminated) {
+                if (hot[0].terminated) {
                     clear_bins();
                     break;
                 }
@@ -855,7 +897,7 @@ struct bfs_search {
                 stats.select_seconds += now() - ts;
             }
         }
-        *value = nodes[0].best_value;
+        *value = hot[0].best_value;
         stats.seconds += now() - t0;
         return 0;
     }
@@ -1132,7 +1174,8 @@ extern "C" int bfs_search_create(bfs_search** out, const bfs_config* cfg) {
         s->tt.assign((size_t)1 << cfg->tt_bits, TTEntry());
         s->nodes.reserve_blocks(s->max_nodes);
         s->up.reset(static_cast<uint32_t*>(std::calloc(s->max_nodes + 1, sizeof(uint32_t))));
-        if (!s->up) throw std::bad_alloc();
+        s->hot.reset(static_cast<Hot*>(std::calloc(s->max_nodes + 1, sizeof(Hot))));
+        if (!s->up || !s->hot) throw std::bad_alloc();
         s->pool.reset(new Pool(threads));       // runs with the workers it could start
         s->eval_lane.reset(new Lane());
         s->policy_lane.reset(new Lane());
