@@ -565,12 +565,16 @@ struct bfs_search {
     // insert_nodes + get_batch (global_open_priority_nodes.py:73-121,143-177).  Nodes leave the bins in the same order
     // as one at a time: candidates are popped in rounds of exactly as many as the batch still lacks, so the last one
     // popped is the one that fills it.
-    std::vector<int> insert_and_get_batch(const std::vector<int>& ids, const std::vector<float>& scores) {
+    // Two phases, because the tree update of the batch before may still run on the evaluation lane while the new nodes
+    // are put into the bins (phase one touches ids, scores, bins and cand only); the walks up the ancestry in phase two
+    // need the update finished (zero_window() joins it between the two).
+    bool small_round = false;
+    void insert_nodes(const std::vector<int>& ids, const std::vector<float>& scores) {
         stats.nodes_in += ids.size();
         wide_now = ids.size() >= wide_batch;
-        std::vector<int> batch;
         cand.clear();
-        if (ids.size() + in_bins < cfg.max_batch_size) {
+        small_round = ids.size() + in_bins < cfg.max_batch_size;
+        if (small_round) {
             for (auto& bin : bins) {
                 auto& b = bin.v;
                 cand.insert(cand.end(), b.rbegin(), b.rend());
@@ -578,7 +582,6 @@ struct bfs_search {
             }
             in_bins = 0;
             cand.insert(cand.end(), ids.begin(), ids.end());
-            keep_live(cand, 0, &batch);
         } else {
             const double ti = now();
             bin_idx.resize(ids.size());
@@ -588,6 +591,13 @@ struct bfs_search {
             for (size_t i = 0; i < ids.size(); ++i) bins[bin_idx[i]].v.push_back(ids[i]);
             in_bins += ids.size();
             stats.select_insert_seconds += now() - ti;
+        }
+    }
+    std::vector<int> get_batch() {
+        std::vector<int> batch;
+        if (small_round) {
+            keep_live(cand, 0, &batch);
+        } else {
             size_t bin = 0;
             while (batch.size() < cfg.max_batch_size && in_bins > 0) {
                 const double tp = now();
@@ -635,6 +645,15 @@ struct bfs_search {
         bfs_search* s;
         size_t n;
     };
+    UpdateCall update_call{};
+    bool update_pending = false;   // the batch's tree update runs on the evaluation lane (iterate() left it there)
+    void finish_update() {         // what of the update is left when everything beside it is done
+        if (!update_pending) return;
+        update_pending = false;
+        const double t0 = now();
+        (void)eval_lane->wait();
+        stats.update_seconds += now() - t0;
+    }
     static int run_update(void* arg) {
         UpdateCall* c = static_cast<UpdateCall*>(arg);
         const double t0 = now();
@@ -675,8 +694,12 @@ struct bfs_search {
     // nothing of the batch may still be running.  (Lane::wait is cheap and idempotent when the lane is idle.)
     struct LanesJoined {
         bfs_search* s;
+        bool leave_update = false;   // a successful iterate() hands its running update to zero_window()
         ~LanesJoined() {
-            (void)s->eval_lane->wait();
+            if (!leave_update) {
+                (void)s->eval_lane->wait();
+                s->update_pending = false;
+            }
             (void)s->policy_lane->wait();
             s->finish_pending = false;
         }
@@ -776,16 +799,16 @@ struct bfs_search {
         // With few host threads the overlap loses: the update then leaves the parents' and the table's lines in
         // another core's cache for the one thread that expands the next batch (depth 5, one thread: 3.3 -> 2.8 M
         // nodes/s; twelve threads: 7.3 -> 7.8 M), so it runs here.
-        UpdateCall update_call{this, n};
+        update_call = UpdateCall{this, n};
         const bool beside = wide_now && pool->threads() >= kOverlapUpdateThreads;
         if (beside) {
             ++stats.overlapped_updates;
             eval_lane->submit(&run_update, &update_call);
+            update_pending = true;
         } else {
             (void)run_update(&update_call);
         }
         if (!beside) { t1 = now(); stats.update_seconds += t1 - t0; t0 = t1; }
-        auto join_update = [&]() { if (beside) (void)eval_lane->wait(); };
         if (int rc = score_end(to_score)) return rc;
         t1 = now(); stats.policy_seconds += t1 - t0; t0 = t1;
         // parents with moves left go back to the open list, open children join it
@@ -824,9 +847,8 @@ struct bfs_search {
             to_insert->push_back((int)(base + i));
             insert_scores->push_back(first_score[i]);
         }
-        t1 = now(); stats.compact_seconds += t1 - t0; t0 = t1;
-        join_update();
-        stats.update_seconds += now() - t0;   // what of the update was left when everything else was done
+        t1 = now(); stats.compact_seconds += t1 - t0;
+        joined.leave_update = true;   // zero_window() joins it (finish_update) after the new nodes are in the bins
         return 0;
     }
 
@@ -885,15 +907,25 @@ struct bfs_search {
             std::vector<int> batch{0}, to_insert;
             std::vector<float> scores;
             stats.nodes_out += 1;
+            struct UpdateJoined {   // nothing of a batch runs on once this function is left, however it is left
+                bfs_search* s;
+                ~UpdateJoined() { s->finish_update(); }
+            } update_joined{this};
             while (!batch.empty()) {
                 if (int rc = iterate(batch, &to_insert, &scores)) return rc;
+                // the batch's tree update may still run (evaluation lane): the new nodes go into the bins beside it
+                const bool nothing_open = to_insert.empty() && in_bins == 0;
+                double ts = now();
+                if (!nothing_open) insert_nodes(to_insert, scores);
+                stats.select_seconds += now() - ts;
+                finish_update();
                 if (hot[0].terminated) {
                     clear_bins();
                     break;
                 }
-                if (to_insert.empty() && in_bins == 0) break;
-                const double ts = now();
-                batch = insert_and_get_batch(to_insert, scores);
+                if (nothing_open) break;
+                ts = now();
+                batch = get_batch();
                 stats.select_seconds += now() - ts;
             }
         }
