@@ -12,19 +12,20 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BATCHFIRST_LIB") or os.path.join(_HERE, "libbatchfirst_hip.so")
 
 BF_OK, BF_E_ARG, BF_E_HIP, BF_E_FORMAT, BF_E_NOGPU = 0, -1, -2, -3, -4
-BF_PRECISION_F32, BF_PRECISION_BF16, BF_PRECISION_F32_SPLIT = 0, 1, 2
+BF_PRECISION_F32, BF_PRECISION_BF16, BF_PRECISION_F32_SPLIT, BF_PRECISION_F32_SPLIT3 = 0, 1, 2, 3
 BF_NOALLOC_MAX_BOARDS = 262144
 BF_SPLIT_BOARDS_DEFAULT = 512
 PRECISIONS = {"f32": BF_PRECISION_F32, "fp32": BF_PRECISION_F32, "float32": BF_PRECISION_F32,
               "bf16": BF_PRECISION_BF16, "bfloat16": BF_PRECISION_BF16,
-              "f32s": BF_PRECISION_F32_SPLIT, "f32_split": BF_PRECISION_F32_SPLIT}
+              "f32s": BF_PRECISION_F32_SPLIT, "f32_split": BF_PRECISION_F32_SPLIT,
+              "f32s3": BF_PRECISION_F32_SPLIT3, "f32_split3": BF_PRECISION_F32_SPLIT3}
 
 
 def precision_code(dtype):
     try:
         return PRECISIONS[str(dtype).replace("torch.", "")]
     except KeyError:
-        raise ValueError("dtype must be 'f32', 'bf16' or 'f32s', got %r" % (dtype,))
+        raise ValueError("dtype must be 'f32', 'bf16', 'f32s' or 'f32s3', got %r" % (dtype,))
 
 _c = ctypes
 _vp, _sz, _int = _c.c_void_p, _c.c_size_t, _c.c_int

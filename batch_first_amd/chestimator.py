@@ -97,7 +97,7 @@ def _finish_closure(finish_fn, handle_fn):
 # boards in two pays when t(2n) > t(n) + the second shard's enqueue (about 10 us).  bf16: t(512) = 40, t(1024) = 47,
 # t(2048) = 75 us -> from 1 024 boards a device; fp32: t(256) = 158, t(512) = 166, t(1024) = 281 us -> from 512.
 # measure_min_shard() repeats the measurement on the box at hand.
-DEFAULT_MIN_SHARD = {"bf16": 1024, "f32": 512, "f32s": 512}
+DEFAULT_MIN_SHARD = {"bf16": 1024, "f32": 512, "f32s": 512, "f32s3": 512}
 
 
 def measure_min_shard(predictor, sizes=(128, 256, 512, 1024, 2048, 4096), reps=9, enqueue_us=10.0):
@@ -133,7 +133,7 @@ class BoardPredictor:
                                               _lib.precision_code(dtype)))
         self._ctx = ctx
         self.dtype = {_lib.BF_PRECISION_F32: "f32", _lib.BF_PRECISION_BF16: "bf16",
-                      _lib.BF_PRECISION_F32_SPLIT: "f32s"}[_lib.precision_code(dtype)]
+                      _lib.BF_PRECISION_F32_SPLIT: "f32s", _lib.BF_PRECISION_F32_SPLIT3: "f32s3"}[_lib.precision_code(dtype)]
         self._closed = False
         self.has_policy = False
         self._close_lock = threading.Lock()

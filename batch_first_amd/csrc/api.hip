@@ -64,7 +64,7 @@ struct bf_ctx : Lane {               // the base is the value network's lane
     // BF_T16_TWO_KERNELS=1 at creation: records always go through k_to_mailbox first (A/B and the equality test);
     // otherwise the 16x16x32 kernel decodes 4-byte-aligned records itself (one launch a call)
     bool two_kernels = false;
-    float* d_packed = nullptr;            // fp32 image (bf_layout.h) when precision is BF_PRECISION_F32 or BF_PRECISION_F32_SPLIT
+    float* d_packed = nullptr;            // fp32 image (bf_layout.h) unless precision is BF_PRECISION_BF16
     unsigned char* d_image16 = nullptr;   // bf16 image (bf_layout_t16.h) when precision == BF_PRECISION_BF16
     // move-scoring network (bf_ctx_set_policy)
     Lane policy;
@@ -148,6 +148,8 @@ std::atomic<size_t> g_split_boards{[] {
     const char* e = std::getenv("BF_SPLIT_BOARDS");
     return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)BF_SPLIT_BOARDS_DEFAULT;
 }()};
+// 0 = float32, 1 = BF_PRECISION_F32_SPLIT, 2 = BF_PRECISION_F32_SPLIT3: what pack_weights and the float32 kernel's launchers take
+int split_level(int precision) { return precision == BF_PRECISION_F32_SPLIT ? 1 : precision == BF_PRECISION_F32_SPLIT3 ? 2 : 0; }
 bool use_split(const bf_ctx* c, size_t n) {
     return c->precision == BF_PRECISION_BF16 && n <= g_split_boards.load(std::memory_order_relaxed);
 }
@@ -158,7 +160,7 @@ hipError_t launch_eval(bf_ctx* c, const uint8_t* d_mailbox, size_t n, float* d_s
         return bf::launch_eval_t16_split(d_mailbox, bf::kMailboxBytes, false, n, c->d_image16, d_scores, s);
     if (c->precision == BF_PRECISION_BF16)
         return bf::launch_eval_t16(d_mailbox, n, c->d_image16, d_scores, d_debug, s);
-    return bf::launch_eval_f32(d_mailbox, n, c->d_packed, d_scores, d_debug, s, c->precision == BF_PRECISION_F32_SPLIT);
+    return bf::launch_eval_f32(d_mailbox, n, c->d_packed, d_scores, d_debug, s, split_level(c->precision));
 }
 
 bf::Workspace workspace(Lane* c) { return bf::Workspace{c->d_local_off, c->d_block_total, c->d_err}; }
@@ -340,7 +342,8 @@ extern "C" int bf_ctx_precision(const bf_ctx* c) { return c ? c->precision : BF_
 extern "C" int bf_ctx_create_ex(bf_ctx** out, int device, const float* h_weights, size_t n_floats, int precision) {
     if (!out || !h_weights) return bf::fail(BF_E_ARG, "bf_ctx_create: null pointer");
     *out = nullptr;
-    if (precision != BF_PRECISION_F32 && precision != BF_PRECISION_BF16 && precision != BF_PRECISION_F32_SPLIT)
+    if (precision != BF_PRECISION_F32 && precision != BF_PRECISION_BF16 && precision != BF_PRECISION_F32_SPLIT &&
+        precision != BF_PRECISION_F32_SPLIT3)
         return bf::fail(BF_E_ARG, "bf_ctx_create: unknown precision %d", precision);
     if (n_floats != bf::kWeightFloats)
         return bf::fail(BF_E_ARG, "bf_ctx_create: expected %zu weight floats, got %zu", bf::kWeightFloats, n_floats);
@@ -375,7 +378,7 @@ extern "C" int bf_ctx_create_ex(bf_ctx** out, int device, const float* h_weights
             return bail(bf::fail(BF_E_HIP, "bf_ctx_create: weight upload failed"));
     } else {
         std::vector<float> packed(bf::kPackedFloats);
-        bf::pack_weights(h_weights, packed.data(), false, precision == BF_PRECISION_F32_SPLIT);
+        bf::pack_weights(h_weights, packed.data(), false, split_level(precision));
         if (hipMalloc(&c->d_packed, bf::kPackedFloats * sizeof(float)) != hipSuccess)
             return bail(bf::fail(BF_E_HIP, "bf_ctx_create: hipMalloc of the weight image failed"));
         if (hipMemcpy(c->d_packed, packed.data(), bf::kPackedFloats * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
@@ -825,7 +828,7 @@ hipError_t launch_policy_features(bf_ctx* c, const uint8_t* d_mailbox, size_t n,
         return bf::launch_policy_features_t16_split(d_mailbox, bf::kMailboxBytes, false, n, c->d_policy_image16, d_x9, s);
     if (c->precision == BF_PRECISION_BF16)
         return bf::launch_policy_features_t16(d_mailbox, n, c->d_policy_image16, d_x9, s);
-    return bf::launch_policy_features_f32(d_mailbox, n, c->d_policy_packed, d_x9, s, c->precision == BF_PRECISION_F32_SPLIT);
+    return bf::launch_policy_features_f32(d_mailbox, n, c->d_policy_packed, d_x9, s, split_level(c->precision));
 }
 
 // Records -> x9 (move-scoring network's tower) on stream `s`, as eval_from_structs.
@@ -878,7 +881,7 @@ extern "C" int bf_ctx_set_policy(bf_ctx* c, const float* h_weights, size_t n_flo
         BF_HIP(hipMemcpy(c->d_policy_image16, image.data(), image.size(), hipMemcpyHostToDevice));
     } else {
         std::vector<float> packed(bf::kPackedFloats);
-        bf::pack_weights(h_weights, packed.data(), true, c->precision == BF_PRECISION_F32_SPLIT);
+        bf::pack_weights(h_weights, packed.data(), true, split_level(c->precision));
         if (!c->d_policy_packed) BF_HIP(hipMalloc(&c->d_policy_packed, bf::kPackedFloats * sizeof(float)));
         BF_HIP(hipMemcpy(c->d_policy_packed, packed.data(), bf::kPackedFloats * sizeof(float), hipMemcpyHostToDevice));
     }

@@ -11,7 +11,7 @@ int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 const char* last_error_text();
 
 // canonical blob -> packed image (bf_layout.h); both sized by the caller
-void pack_weights(const float* blob, float* packed, bool policy = false, bool split = false);   // split: BF_PRECISION_F32_SPLIT
+void pack_weights(const float* blob, float* packed, bool policy = false, int split = 0);   // split: 1 BF_PRECISION_F32_SPLIT, 2 BF_PRECISION_F32_SPLIT3
 
 
 // canonical blob -> image of the 16x16x32 bf16 kernel (bf_layout_t16.h), t16::kImageBytes bytes

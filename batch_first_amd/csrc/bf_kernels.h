@@ -31,14 +31,15 @@ hipError_t launch_planes_from_mailbox(const uint8_t* d_mailbox, size_t n, float*
 // The value network: mailboxes -> scores.  `d_packed` is the image bf::pack_weights builds.
 // `d_debug` (nullable) receives every intermediate activation, kDebugFloatsPerBoard per board.
 constexpr size_t kDebugFloatsPerBoard = 64 * (236 + 128 + 6 * 32) + 16;
-// split: the image was packed for, and the kernel runs, the 1x1 pair as two-term bf16 products (BF_PRECISION_F32_SPLIT).
+// split: the level the image was packed for and the kernel runs at: 0 float32, 1 BF_PRECISION_F32_SPLIT (1x1 pair as
+// two-term, 3x3 layers as three-term bf16 products), 2 BF_PRECISION_F32_SPLIT3 (three terms everywhere).
 hipError_t launch_eval_f32(const uint8_t* d_mailbox, size_t n, const float* d_packed, float* d_scores,
-                           float* d_debug, hipStream_t stream, bool split = false);
+                           float* d_debug, hipStream_t stream, int split = 0);
 
 // The move-scoring network (packed with pack_weights(..., policy = true)): mailboxes -> x9 features
 // float32 [n][32][64]; then one logit per requested move.
 hipError_t launch_policy_features_f32(const uint8_t* d_mailbox, size_t n, const float* d_packed, float* d_x9,
-                                      hipStream_t stream, bool split = false);
+                                      hipStream_t stream, int split = 0);
 // d_logit_w: the logit kernel as float32 [73][32] (both images keep it at their head offset)
 hipError_t launch_policy_scores(const float* d_x9, const float* d_logit_w, const unsigned* d_board_index,
                                 const uint8_t* d_from, const uint8_t* d_filter, size_t n_moves, size_t n_boards,

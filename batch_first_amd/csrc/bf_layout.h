@@ -64,11 +64,14 @@ constexpr int kStreamGroups = kInputGroups + kC2Tiles * kPerC2Groups + kConv4Gro
 // of 16 channels x 3 bf16 terms of the kernels, one group (one v_mfma_f32_32x32x16_bf16 A fragment) each
 constexpr int kConvSplitChunkGroups = 9 * 2 * 3;           // 54
 constexpr int kStreamGroupsSplit = kInputGroups + kC2Tiles * kPerC2Groups + 10 * kConvSplitChunkGroups;  // 1516
+// BF_PRECISION_F32_SPLIT3: the pair with three terms a side too: 15 + 8 k-steps of 16, three kernel terms each
+constexpr int kPerC2GroupsSplit3 = (15 + 8) * 3;           // 69
+constexpr int kStreamGroupsSplit3 = kInputGroups + kC2Tiles * kPerC2GroupsSplit3 + 10 * kConvSplitChunkGroups;  // 1884
 constexpr int kStreamChunk = 8;       // groups a workgroup walks between two barriers (eval_f32.hip)
 constexpr int kStreamPadGroups = 32;  // prefetch runs up to three chunks past the end
-// one image size for both precisions (the float32 stream leaves the tail of the region unused)
-constexpr size_t kStreamFloats = (size_t)(kStreamGroupsSplit + kStreamPadGroups) * kGroupFloats;
-static_assert(kStreamGroupsSplit >= kStreamGroups, "");
+// one image size for all three precisions (the shorter streams leave the tail of the region unused)
+constexpr size_t kStreamFloats = (size_t)(kStreamGroupsSplit3 + kStreamPadGroups) * kGroupFloats;
+static_assert(kStreamGroupsSplit3 >= kStreamGroupsSplit && kStreamGroupsSplit >= kStreamGroups, "");
 
 // bias table: folded batch-norm shift per channel, layers back to back
 constexpr int kBiasX1 = 0, kBiasX2 = 236, kBiasX3 = 748, kBiasX4 = 876;  // x4..x9: 32 each

@@ -61,7 +61,7 @@ constexpr int BPB = BF_BPB;            // boards per workgroup
 constexpr int WAVES = 2 * BPB;
 constexpr int THREADS = 64 * WAVES;
 constexpr int CHUNK = kStreamChunk;    // groups per lockstep chunk
-constexpr int SHARE = CHUNK / WAVES;   // groups each wave fetches per chunk
+// (a wave fetches CHUNK / WAVES groups of every chunk: WStreamT::SHARE)
 constexpr int SLOTS = 3;
 // BF_PRECISION_F32_SPLIT consumes a group every two 32-cycle MFMAs (the float32 form: every four 64-cycle ones), so a
 // chunk lasts 512 cycles instead of 2048 and a fetch has two barriers = 0.4 us to land.  Measured with 3, 4 and 5
@@ -71,6 +71,10 @@ constexpr int SLOTS = 3;
 #define BF_F32_SPLIT_SLOTS 3
 #endif
 constexpr int SPLIT_SLOTS = BF_F32_SPLIT_SLOTS;
+// SPLIT level 2 (BF_PRECISION_F32_SPLIT3) keeps the third term of x1 in LDS (60 KB a workgroup), so its ring has
+// chunks of 4 groups: 12 KB, two workgroups a CU as for the other two forms.
+constexpr int chunk_of(int split) { return split == 2 ? 4 : CHUNK; }
+constexpr int slots_of(int split) { return split ? SPLIT_SLOTS : SLOTS; }
 #ifndef BF_F32_LA
 #define BF_F32_LA 3
 #endif
@@ -78,11 +82,12 @@ constexpr int SPLIT_SLOTS = BF_F32_SPLIT_SLOTS;
 // stage 1 a group feeds ONE 32-cycle MFMA, and with a single group in flight every one of its 240 steps sat
 // out an LDS read (stamps, one wave per SIMD: 23.8 k cycles for 7.7 k cycles of MFMA work).
 constexpr int LA = BF_F32_LA;
-static_assert(LA >= 1 && LA <= 3 && CHUNK % (LA + 1) == 0, "the look-ahead ring must keep its phase over a chunk");
+static_assert(LA >= 1 && LA <= 3 && CHUNK % (LA + 1) == 0 && chunk_of(2) % (LA + 1) == 0, "the look-ahead ring must keep its phase over a chunk");
 constexpr int C2_UNROLL = 4;           // hidden tiles per loop body: 4 * 46 groups = 23 chunks
-static_assert(CHUNK % WAVES == 0, "every wave fetches whole groups");
+static_assert(CHUNK % WAVES == 0 && chunk_of(2) % WAVES == 0, "every wave fetches whole groups");
 static_assert(kInputGroups % CHUNK == 0, "the tile loop must start on a chunk boundary");
 static_assert((kPerC2Groups * C2_UNROLL) % CHUNK == 0, "loop body must be whole chunks");
+static_assert((kPerC2GroupsSplit3 * C2_UNROLL) % chunk_of(2) == 0, "loop body must be whole chunks");
 static_assert(kC2Tiles % C2_UNROLL == 0, "");
 static_assert(kStreamPadGroups >= SPLIT_SLOTS * CHUNK + LA && kStreamPadGroups >= 3 * CHUNK + LA, "prefetch overrun must stay inside the image");
 
@@ -102,11 +107,17 @@ constexpr int XS_PLANE_BYTES = XP_PLANE * XS_POS_BYTES;   // 6 400
 constexpr int XS_FLOATS = 3 * XS_PLANE_BYTES / 4;         // 4 800
 static_assert(128 * RED_STRIDE <= XS_FLOATS, "the head's reduction scratch aliases the activation planes");
 
-template <bool SPLIT>
+// SPLIT level 2: the third bf16 term of x1, per wave [15 k-steps][64 lanes] x 16 bytes (the B fragment of
+// v_mfma_f32_32x32x16_bf16, lane-linear: wave-private, conflict-free), in the space the term planes take afterwards.
+constexpr int X1LO_WAVE_FLOATS = 15 * 64 * 4;             // 15 KB
+static_assert(2 * X1LO_WAVE_FLOATS >= XS_FLOATS, "the term planes alias the x1 region");
+
+template <int SPLIT>
 struct LdsT {
-    f32x4 wring[SPLIT ? SPLIT_SLOTS : SLOTS][CHUNK][64];   // shared A-fragment ring
-    // per board: two alternating zero-haloed activation buffers (float32), or the three term planes
-    float xbuf[BPB][SPLIT ? 1 : 2][SPLIT ? XS_FLOATS : XBUF_FLOATS];
+    f32x4 wring[slots_of(SPLIT)][chunk_of(SPLIT)][64];   // shared A-fragment ring
+    // per board: two alternating zero-haloed activation buffers (float32), or the three term planes (level 2: in the
+    // space that holds the third term of x1 during the 1x1 pair)
+    float xbuf[BPB][SPLIT ? 1 : 2][SPLIT == 2 ? 2 * X1LO_WAVE_FLOATS : SPLIT ? XS_FLOATS : XBUF_FLOATS];
     unsigned char mb[BPB][MB_BYTES];     // per board: padded code mailbox
 #ifdef BF_ABL_LDSPAD
     char pad[20000];
@@ -114,8 +125,9 @@ struct LdsT {
 };
 
 // Lockstep walk over the A-fragment stream through the LDS ring of S slots.
-template <int S>
+template <int S, int C>
 struct WStreamT {
+    static constexpr int CHUNK = C, SHARE = C / WAVES;   // (shadow the file-scope float32 values)
     const f32x4* src;      // this lane's element of this wave's share of the chunk to fetch next
     f32x4* ring;           // &lds.wring[0][0][lane]
     unsigned lds_share;    // LDS byte address of &lds.wring[0][wave * SHARE][0]: where this wave's share of slot 0 lands
@@ -362,7 +374,7 @@ __device__ __forceinline__ void conv3x3_chunk_split(WStream& ws, int g0, const c
 // float32 sums: 92 32-cycle MFMAs a hidden tile instead of 183 64-cycle ones (same stream shape, 30 + 16 groups a
 // hidden tile, other contents: pack.cpp); and the six 3x3 layers with both operands as THREE bf16 terms
 // (conv3x3_chunk_split).  Stage 1 and the head are this kernel unchanged.
-template <int MODE, bool SPLIT>
+template <int MODE, int SPLIT>
 __global__ __launch_bounds__(THREADS, 2) void k_eval_f32(const uint8_t* __restrict__ mailbox, unsigned n_boards,
                                                           const f32x4* __restrict__ wstream,
                                                           const float* __restrict__ bias,
@@ -385,12 +397,12 @@ __global__ __launch_bounds__(THREADS, 2) void k_eval_f32(const uint8_t* __restri
     long long stamps[12];
 #endif
     BF_STAMP(0);
-    WStreamT<SPLIT ? SPLIT_SLOTS : SLOTS> ws;
+    WStreamT<slots_of(SPLIT), chunk_of(SPLIT)> ws;
     ws.prime(wstream, &lds.wring[0][0][0], lane, wave);
 
     // ---- LDS set-up: empty mailbox (0xFF everywhere), zero activation planes ------------
     if (btid < MB_BYTES / 4) reinterpret_cast<unsigned*>(lds.mb[bib])[btid] = 0xFFFFFFFFu;
-    {
+    if (SPLIT != 2) {   // (level 2 zeroes its planes after the 1x1 pair, when the x1 region they alias is free)
         f32x4* z = reinterpret_cast<f32x4*>(&lds.xbuf[bib][0][0]);
         for (int i = btid; i < (int)(sizeof(lds.xbuf[0]) / 16); i += 128) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -433,7 +445,78 @@ __global__ __launch_bounds__(THREADS, 2) void k_eval_f32(const uint8_t* __restri
         for (int t = 0; t < 16; ++t)
             acc3[c3][t] = pick(hl, bias[kBiasX3 + 32 * c3 + rowmap(t, 0)], bias[kBiasX3 + 32 * c3 + rowmap(t, 1)]);
 
-    if (SPLIT) {
+    if (SPLIT == 2) {
+        // BF_PRECISION_F32_SPLIT3: three terms a side, the six products of conv3x3_chunk_split.  x1's hi and mid terms
+        // stay in registers as in level 1; the third term goes to this wave's own LDS region as ready-made B
+        // fragments, one ds_read_b128 a k-step and hidden tile (120 + 60 registers would leave one wave per SIMD).
+        unsigned xs[2][60];
+        u32x4* x1lo = reinterpret_cast<u32x4*>(&lds.xbuf[bib][0][half * X1LO_WAVE_FLOATS]) + lane;
+#pragma unroll
+        for (int s = 0; s < 15; ++s) {
+            u32x4 lo4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int d = 4 * s + j;
+                const float a = 2 * d < kX1Regs ? x1[2 * d] : (2 * d == kX1Regs ? pick(hl, 1.0f, 0.0f) : 0.0f);
+                const float b = 2 * d + 1 < kX1Regs ? x1[2 * d + 1] : 0.0f;
+                unsigned l_;
+                split3(a, b, xs[0][d], xs[1][d], l_);
+                lo4[j] = l_;
+            }
+            x1lo[s * 64] = lo4;
+        }
+        u32x4 xl[2];
+        xl[0] = x1lo[0];
+#pragma unroll 1
+        for (int it = 0; it < kC2Tiles / C2_UNROLL; ++it) {
+#pragma unroll
+            for (int u = 0; u < C2_UNROLL; ++u) {
+                const int g0 = kInputGroups + u * kPerC2GroupsSplit3;
+                f32x16 acc2 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 15; ++s) {
+                    xl[(s + 1) & 1] = x1lo[((s + 1) % 15) * 64];   // (the last one is the next tile's first)
+                    const f32x4 wh = ws.take(g0 + 3 * s), wm = ws.take(g0 + 3 * s + 1), wl = ws.take(g0 + 3 * s + 2);
+                    const u32x4 xh = u32x4{xs[0][4 * s], xs[0][4 * s + 1], xs[0][4 * s + 2], xs[0][4 * s + 3]};
+                    const u32x4 xm = u32x4{xs[1][4 * s], xs[1][4 * s + 1], xs[1][4 * s + 2], xs[1][4 * s + 3]};
+                    acc2 = BF_MFMA16(wl, xh, acc2);
+                    acc2 = BF_MFMA16(wh, xl[s & 1], acc2);
+                    acc2 = BF_MFMA16(wm, xm, acc2);
+                    acc2 = BF_MFMA16(wm, xh, acc2);
+                    acc2 = BF_MFMA16(wh, xm, acc2);
+                    acc2 = BF_MFMA16(wh, xh, acc2);
+                }
+                // 15 is odd: after a tile the fragment for s = 0 sits in xl[1]; keep the parity the loop expects
+                xl[0] = xl[1];
+                unsigned hs[3][8];
+#pragma unroll
+                for (int d = 0; d < 8; ++d) split3(relu(acc2[2 * d]), relu(acc2[2 * d + 1]), hs[0][d], hs[1][d], hs[2][d]);
+#pragma unroll
+                for (int c3 = 0; c3 < 4; ++c3)
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) {
+                        const int g = g0 + 45 + (c3 * 2 + v) * 3;
+                        const f32x4 wh = ws.take(g), wm = ws.take(g + 1), wl = ws.take(g + 2);
+                        const u32x4 hh = u32x4{hs[0][4 * v], hs[0][4 * v + 1], hs[0][4 * v + 2], hs[0][4 * v + 3]};
+                        const u32x4 hm = u32x4{hs[1][4 * v], hs[1][4 * v + 1], hs[1][4 * v + 2], hs[1][4 * v + 3]};
+                        const u32x4 hl_ = u32x4{hs[2][4 * v], hs[2][4 * v + 1], hs[2][4 * v + 2], hs[2][4 * v + 3]};
+                        acc3[c3] = BF_MFMA16(wl, hh, acc3[c3]);
+                        acc3[c3] = BF_MFMA16(wh, hl_, acc3[c3]);
+                        acc3[c3] = BF_MFMA16(wm, hm, acc3[c3]);
+                        acc3[c3] = BF_MFMA16(wm, hh, acc3[c3]);
+                        acc3[c3] = BF_MFMA16(wh, hm, acc3[c3]);
+                        acc3[c3] = BF_MFMA16(wh, hh, acc3[c3]);
+                    }
+            }
+        }
+        // the term planes of the 3x3 layers take the x1 region's place: both halves of the board are done with it
+        __syncthreads();
+        {
+            f32x4* z = reinterpret_cast<f32x4*>(&lds.xbuf[bib][0][0]);
+            for (int i = btid; i < XS_FLOATS / 4; i += 128) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();
+    } else if (SPLIT) {
         // x1 as two bf16 terms, packed for the B operand of v_mfma_f32_32x32x16_bf16: k-step s takes registers
         // 8s .. 8s+7 (element j of lane half h = channel 16s + 2j + h); register 118 of half 0 is the all-ones slot
         // that carries the hidden layer's shift, the rest of the padding is zero.
@@ -710,22 +793,33 @@ __global__ __launch_bounds__(256) void k_policy_scores(const float* __restrict__
 
 }  // namespace
 
-hipError_t launch_policy_features_f32(const uint8_t* d_mailbox, size_t n, const float* d_packed, float* d_x9,
-                                      hipStream_t stream, bool split) {
-    if (n == 0) return hipSuccess;
-#ifdef BF_ONLY_SPLIT_SCORES   // experiment builds (tools/build_variant.sh): k_eval_f32<0, true> alone is instantiated
-    return hipErrorNotSupported;
-#else
-    const f32x4* ws = reinterpret_cast<const f32x4*>(d_packed + kOffStream);
-    const unsigned blocks = (unsigned)((n + BPB - 1) / BPB);
-    if (split)
-        hipLaunchKernelGGL((k_eval_f32<2, true>), dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, (unsigned)n, ws,
-                           d_packed + kOffBias, reinterpret_cast<const f32x4*>(d_packed + kOffHead), d_x9, nullptr);
-    else
-        hipLaunchKernelGGL((k_eval_f32<2, false>), dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, (unsigned)n, ws,
-                           d_packed + kOffBias, reinterpret_cast<const f32x4*>(d_packed + kOffHead), d_x9, nullptr);
-    return hipGetLastError();
+// split: 0 = float32, 1 = BF_PRECISION_F32_SPLIT, 2 = BF_PRECISION_F32_SPLIT3
+template <int MODE>
+static hipError_t launch_mode(int split, unsigned blocks, hipStream_t stream, const uint8_t* d_mailbox, unsigned n, const f32x4* ws,
+                              const float* bias, const f32x4* head, float* out, float* dbg) {
+#ifdef BF_ONLY_SPLIT_SCORES   // experiment builds (tools/build_variant.sh): one instantiation, k_eval_f32<0, BF_ONLY_SPLIT_VALUE>
+#ifndef BF_ONLY_SPLIT_VALUE
+#define BF_ONLY_SPLIT_VALUE 1
 #endif
+    if (MODE != 0 || split != BF_ONLY_SPLIT_VALUE) return hipErrorNotSupported;
+    hipLaunchKernelGGL((k_eval_f32<0, BF_ONLY_SPLIT_VALUE>), dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, n, ws, bias, head, out, dbg);
+#else
+    if (split == 2)
+        hipLaunchKernelGGL((k_eval_f32<MODE, 2>), dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, n, ws, bias, head, out, dbg);
+    else if (split == 1)
+        hipLaunchKernelGGL((k_eval_f32<MODE, 1>), dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, n, ws, bias, head, out, dbg);
+    else
+        hipLaunchKernelGGL((k_eval_f32<MODE, 0>), dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, n, ws, bias, head, out, dbg);
+#endif
+    return hipGetLastError();
+}
+
+hipError_t launch_policy_features_f32(const uint8_t* d_mailbox, size_t n, const float* d_packed, float* d_x9,
+                                      hipStream_t stream, int split) {
+    if (n == 0) return hipSuccess;
+    return launch_mode<2>(split, (unsigned)((n + BPB - 1) / BPB), stream, d_mailbox, (unsigned)n,
+                          reinterpret_cast<const f32x4*>(d_packed + kOffStream), d_packed + kOffBias,
+                          reinterpret_cast<const f32x4*>(d_packed + kOffHead), d_x9, nullptr);
 }
 
 hipError_t launch_policy_scores(const float* d_x9, const float* d_logit_w, const unsigned* d_board_index,
@@ -739,40 +833,17 @@ hipError_t launch_policy_scores(const float* d_x9, const float* d_logit_w, const
 }
 
 hipError_t launch_eval_f32(const uint8_t* d_mailbox, size_t n, const float* d_packed, float* d_scores,
-                           float* d_debug, hipStream_t stream, bool split) {
+                           float* d_debug, hipStream_t stream, int split) {
     if (n == 0) return hipSuccess;
     const f32x4* ws = reinterpret_cast<const f32x4*>(d_packed + kOffStream);
     const float* bias = d_packed + kOffBias;
     const f32x4* head = reinterpret_cast<const f32x4*>(d_packed + kOffHead);
     const unsigned blocks = (unsigned)((n + BPB - 1) / BPB);
-#ifdef BF_ONLY_SPLIT_SCORES
-#ifndef BF_ONLY_SPLIT_VALUE
-#define BF_ONLY_SPLIT_VALUE true
-#endif
-    if (split != BF_ONLY_SPLIT_VALUE) return hipErrorNotSupported;
-    hipLaunchKernelGGL((k_eval_f32<0, BF_ONLY_SPLIT_VALUE>), dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, (unsigned)n, ws, bias, head,
-                       d_scores, d_debug);
-    return hipGetLastError();
+#ifdef BF_STAMPS   // the debug pointer carries the stamps of the scores kernel
+    return launch_mode<0>(split, blocks, stream, d_mailbox, (unsigned)n, ws, bias, head, d_scores, d_debug);
 #else
-#ifdef BF_STAMPS
-    if (false)
-#else
-    if (d_debug)
-#endif
-    {
-        if (split)
-            hipLaunchKernelGGL((k_eval_f32<1, true>), dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, (unsigned)n, ws,
-                               bias, head, d_scores, d_debug);
-        else
-            hipLaunchKernelGGL((k_eval_f32<1, false>), dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, (unsigned)n, ws,
-                               bias, head, d_scores, d_debug);
-    } else if (split)
-        hipLaunchKernelGGL((k_eval_f32<0, true>), dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, (unsigned)n, ws,
-                           bias, head, d_scores, d_debug);
-    else
-        hipLaunchKernelGGL((k_eval_f32<0, false>), dim3(blocks), dim3(THREADS), 0, stream, d_mailbox, (unsigned)n, ws,
-                           bias, head, d_scores, d_debug);
-    return hipGetLastError();
+    if (d_debug) return launch_mode<1>(split, blocks, stream, d_mailbox, (unsigned)n, ws, bias, head, d_scores, d_debug);
+    return launch_mode<0>(split, blocks, stream, d_mailbox, (unsigned)n, ws, bias, head, d_scores, d_debug);
 #endif
 }
 

@@ -88,7 +88,7 @@ void split_bf16x3(float w, uint16_t out[3]) {
 
 }  // namespace
 
-void pack_weights(const float* blob, float* packed, bool policy, bool split) {
+void pack_weights(const float* blob, float* packed, bool policy, int split) {
     const Canonical c = slice(blob, policy);
     std::memset(packed, 0, kPackedFloats * sizeof(float));
 
@@ -147,15 +147,17 @@ void pack_weights(const float* blob, float* packed, bool policy, bool split) {
     // terms (hi, then mid = bf16(w - hi)) in consecutive groups.  236 -> 512: k-step s, element (h, j) = input channel
     // 16 s + 2 j + h (x1 register 8 s + j of lane half h); channel slot 236 holds the folded shift (its B element is
     // 1.0).  512 -> 128: k-step v, element (h, j) = hidden row rowmap(8 v + j, h) (accumulator register 8 v + j).
+    // split level 2 (BF_PRECISION_F32_SPLIT3): the same with three terms (hi, mid, lo), 45 + 24 groups a tile.
     if (split) {
-        auto put_terms = [&](auto value_of) {   // value_of(lane, j) -> float; writes the hi group, then the mid group
-            for (int term = 0; term < 2; ++term) {
+        const int terms = split == 2 ? 3 : 2;
+        auto put_terms = [&](auto value_of) {   // value_of(lane, j) -> float; writes the hi group, then mid (then lo)
+            for (int term = 0; term < terms; ++term) {
                 uint16_t* grp = reinterpret_cast<uint16_t*>(stream + (kstep >> 2) * kGroupFloats);
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 8; ++j) {
-                        const float v = value_of(lane, j);
-                        const uint16_t hi = bf16_rne(v);
-                        grp[lane * 8 + j] = term == 0 ? hi : bf16_rne(v - bf16_to_float(hi));
+                        uint16_t parts[3];
+                        split_bf16x3(value_of(lane, j), parts);   // (two terms: the first two of the three)
+                        grp[lane * 8 + j] = parts[term];
                     }
                 kstep += 4;
             }

@@ -246,19 +246,17 @@ def main():
     # boards/s, the kernel time beside k_eval_f32's, and the bf16 MFMA work the kernel EXECUTES per board (2 waves x
     # (240 + 16 x 92 + 10 x 108) v_mfma_f32_32x32x16_bf16 of 32 768 FLOP: 5.2 x the algorithmic FLOPs, that is the
     # price of the terms) against the bf16 peak
-    split = None
-    if not bf16:
-        s_elapsed, s_kernel_ms, _, s_ctx = measure("f32s")
-        mfma_per_board = 2 * (240 + 16 * 92 + 10 * 108)
+    def split_block(dtype, code, mfma_per_wave, what):
+        s_elapsed, s_kernel_ms, _, s_ctx = measure(dtype)
+        mfma_per_board = 2 * mfma_per_wave
         executed = mfma_per_board * 32768
         s_tflops = executed * n_kernel / (s_kernel_ms * 1e-3) / 1e12
-        split = {"value": total_boards * args.steps / s_elapsed, "unit": "boards/s", "steps": args.steps, "warmup": args.warmup,
-                 "ms_per_step": 1e3 * s_elapsed / args.steps, "dtype": "f32s",
-                 "config": {"workload": "BF_PRECISION_F32_SPLIT on the headline's records and batch: 236->512->128 pair as "
-                                        "(hi+mid) x (hi+mid) bf16, six 3x3 layers as (hi+mid+lo) x (hi+mid+lo) bf16 (six "
-                                        "products), fp32 sums, stage 1 and head as the fp32 kernel (scores within the fp32 "
-                                        "kernel's 1e-4 bound, tests/test_gpu_parity.py)"},
-                 "kernel": "k_eval_f32<0, SPLIT>", "kernel_ms": s_kernel_ms, "kernel_ms_f32": kernel_ms,
+        block = {"value": total_boards * args.steps / s_elapsed, "unit": "boards/s", "steps": args.steps, "warmup": args.warmup,
+                 "ms_per_step": 1e3 * s_elapsed / args.steps, "dtype": dtype,
+                 "config": {"workload": code + " on the headline's records and batch: " + what + ", fp32 sums, stage 1 and "
+                                        "head as the fp32 kernel (scores within the fp32 kernel's 1e-4 bound, "
+                                        "tests/test_gpu_parity.py)"},
+                 "kernel": "k_eval_f32<0, %d>" % (1 if dtype == "f32s" else 2), "kernel_ms": s_kernel_ms, "kernel_ms_f32": kernel_ms,
                  "speedup_over_f32_kernel": kernel_ms / s_kernel_ms,
                  "executed_bf16": {"mfma_per_board": mfma_per_board, "flops_per_board": executed, "achieved": s_tflops,
                                    "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -268,6 +266,16 @@ def main():
                                            "a utilisation figure for this kernel, not comparable with the roofline "
                                            "fractions above"}}
         s_ctx.close()
+        return block
+
+    split = split3 = None
+    if not bf16:
+        split = split_block("f32s", "BF_PRECISION_F32_SPLIT", 240 + 16 * 92 + 10 * 108,
+                            "236->512->128 pair as (hi+mid) x (hi+mid) bf16, six 3x3 layers as (hi+mid+lo) x (hi+mid+lo) "
+                            "bf16 (six products)")
+        split3 = split_block("f32s3", "BF_PRECISION_F32_SPLIT3", 240 + 16 * 138 + 10 * 108,
+                             "236->512->128 pair and six 3x3 layers as (hi+mid+lo) x (hi+mid+lo) bf16 (six products): every "
+                             "matrix product at 24 significant bits, scores as close to the oracle as the fp32 kernel's")
     if shard:
         recs = recs[:65536].contiguous()
         n = 65536
@@ -346,6 +354,7 @@ def main():
             out["bf16"] = other
         if split is not None:
             out["f32s"] = split
+            out["f32s3"] = split3
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

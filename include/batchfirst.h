@@ -75,13 +75,18 @@ enum {
  *                      (round-to-nearest-even), float32 sums, shifts, x10 and logit
  *                      (v_mfma_f32_16x16x32_bf16).  No reference counterpart: the reference runs
  *                      TensorRT/TensorFlow in FP32 only (ann_creation_helper.py:182-187).
- *   BF_PRECISION_F32_SPLIT  the F32 kernel with its 1x1 pair (236 -> 512 -> 128, 68 % of the network's FLOPs) on
- *                      v_mfma_f32_32x32x16_bf16: kernels and activations of those two layers as TWO bf16 terms each
- *                      (hi + mid = 16 significant bits), all four products, float32 sums; input convolutions, 3x3
- *                      layers, head and every shift as in F32.  Scores within 1e-4 relative of the float32
- *                      evaluation (measured worst 0.6 of that bound on the golden sets, F32 itself 0.08), not bit-equal
- *                      to F32's; 1.8 times F32's boards per second.  No reference counterpart (as BF16). */
-enum { BF_PRECISION_F32 = 0, BF_PRECISION_BF16 = 1, BF_PRECISION_F32_SPLIT = 2 };
+ *   BF_PRECISION_F32_SPLIT  the F32 kernel's structure with the layers that take 97 % of its matrix time on
+ *                      v_mfma_f32_32x32x16_bf16, as sums of bf16 x bf16 products with float32 accumulation: the 1x1
+ *                      pair (236 -> 512 -> 128) with kernels and activations as TWO bf16 terms each (hi + mid = 16
+ *                      significant bits, four products), the six 3x3 layers with THREE terms each (24 bits, the six
+ *                      products that matter); input convolutions, head and every shift as in F32.  Scores within
+ *                      1e-4 relative of the float32 evaluation (measured worst 0.62 of that bound on the golden sets,
+ *                      F32 itself 0.08), not bit-equal to F32's; 2.1-2.2 times F32's boards per second.
+ *   BF_PRECISION_F32_SPLIT3  the same with THREE terms in the 1x1 pair as well (the third term of the 236-channel
+ *                      activation lives in LDS): every matrix product carries 24 significant bits, scores as close
+ *                      to the float32 evaluation as F32's own (measured worst 0.11 of the bound, F32 0.08); 1.7 times F32's boards per
+ *                      second (F32_SPLIT: 2.2).  Neither has a reference counterpart (as BF16). */
+enum { BF_PRECISION_F32 = 0, BF_PRECISION_BF16 = 1, BF_PRECISION_F32_SPLIT = 2, BF_PRECISION_F32_SPLIT3 = 3 };
 
 typedef struct bf_ctx bf_ctx;
 

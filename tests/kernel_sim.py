@@ -11,7 +11,7 @@ INPUT_CONVS = [(3, 1, 1, 64, 0, 2), (3, 2, 2, 32, 64, 1), (3, 3, 3, 20, 96, 1), 
                (3, 5, 5, 18, 136, 1), (3, 6, 6, 18, 154, 1), (3, 7, 7, 16, 172, 1), (2, 2, 4, 24, 188, 1),
                (2, 4, 2, 24, 212, 1)]
 STREAM_GROUPS = 1300
-STREAM_REGION = 1516 + 32   # groups the image reserves: the split precision's stream (bf_layout.h: kStreamGroupsSplit) + padding
+STREAM_REGION = 1884 + 32   # groups the image reserves: the longest stream (bf_layout.h: kStreamGroupsSplit3) + padding
 BIAS_FLOATS = 1104
 B_X1, B_X2, B_X3, B_X4, B_X10, B_LOGIT = 0, 236, 748, 876, 1068, 1084
 

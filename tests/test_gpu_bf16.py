@@ -310,15 +310,16 @@ def test_bf16_move_ordering_on_real_sibling_groups(predictor16, siblings):
     assert rep["flipped_below_gap"] < 0.03 * rep["pairs"]
 
 
-def test_f32_split_move_ordering_on_real_sibling_groups(weights, siblings):
+@pytest.mark.parametrize("dtype", ["f32s", "f32s3"])
+def test_f32_split_move_ordering_on_real_sibling_groups(weights, siblings, dtype):
     """BF_PRECISION_F32_SPLIT on the same sibling groups (the ordering the bf16
     precision loses, bought back): scores inside the float32 bound, every pair and every arg-max that float32
     separates by more than four times that bound kept, and over ALL pairs the line asked of a repaired bf16 kernel:
     at least 126 of 128 arg-maxima and under 0.5 % flipped pairs (measured: see the printed line)."""
     from batch_first_amd import chestimator
-    bp, _, closer = chestimator.get_inference_functions(weights, dtype="f32s")
+    bp, _, closer = chestimator.get_inference_functions(weights, dtype=dtype)
     try:
-        assert bp.dtype == "f32s"
+        assert bp.dtype == dtype
         structs = np.frombuffer(siblings["records"].tobytes(), dtype=P.COMPACT_DTYPE)
         got = bp.eval_structs(structs)
         again = bp(siblings["piece_filters"], siblings["occupied_bbs"])
@@ -329,7 +330,7 @@ def test_f32_split_move_ordering_on_real_sibling_groups(weights, siblings):
     e, rms = _rel(got, ref)
     sizes = siblings["group_sizes"]
     rep = ordering_report(got, ref, sizes, 4e-4 * rms)
-    print("f32s siblings: worst vs fp32 oracle %.2e (bound 1e-4); above 4e-4 rms: %d arg-maxima, %d pairs kept; "
+    print(dtype + " siblings: worst vs fp32 oracle %.2e (bound 1e-4); above 4e-4 rms: %d arg-maxima, %d pairs kept; "
           "over all pairs %d of %d flipped, %d of 128 arg-maxima moved"
           % (e.max(), rep["top_checked"], rep["pairs_checked"], rep["flipped_below_gap"], rep["pairs"], rep["argmax_moved"]))
     assert e.max() <= 1e-4

@@ -225,7 +225,7 @@ def test_policy_bf16_precision(pweights, pgolden, golden):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype", ["f32", "f32s", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "f32s", "f32s3", "bf16"])
 def test_policy_orders_the_legal_moves_of_real_parents(pweights, dtype):
     """The move-scoring network on what the search feeds it: the 128 parents of
     tests/golden/siblings_128.npz with ALL their legal moves as requests in the mover's frame

@@ -2,7 +2,7 @@
 per-launch HBM bytes should not carry another kernel's dirty lines: VERDICT round 2, "make the traffic figure
 reproducible").
 
-    python tools/kernel_only.py f32|f32s|bf16 [launches] [n]
+    python tools/kernel_only.py f32|f32s|f32s3|bf16 [launches] [n]
 
 f32: k_eval_f32 on mailboxes made by ONE k_to_mailbox launch before a two-second pause; bf16: k_eval_t16<4>, which
 takes the records themselves (the kernel bench.py's timed step launches).  Prints the kernel's source hash, which
@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 
 def source_sha16(dtype):
     f32 = ["eval_f32.hip", "bf_layout.h", "pack.cpp"]
-    files = {"f32": f32, "f32s": f32, "bf16": ["eval_t16.hip", "t16_common.h", "bf_layout_t16.h", "pack_t16.cpp"]}[dtype]
+    files = {"f32": f32, "f32s": f32, "f32s3": f32, "bf16": ["eval_t16.hip", "t16_common.h", "bf_layout_t16.h", "pack_t16.cpp"]}[dtype]
     h = hashlib.sha256()
     for f in files:
         with open(os.path.join(ROOT, "batch_first_amd", "csrc", f), "rb") as fh:

@@ -3,7 +3,7 @@
 #   gpurun -- 'bash tools/pmc_alone.sh <tag>'   ->  gpurun_out/<tag>/pmc_alone_{f32,bf16}.json
 set -e -o pipefail
 tag=${1:-pmc_alone}; out=gpurun_out/$tag; mkdir -p "$out"; export TMPDIR=/tmp
-for dt in ${PMC_DTYPES:-f32 f32s bf16}; do
+for dt in ${PMC_DTYPES:-f32 f32s f32s3 bf16}; do
   k=k_eval_f32; [ $dt = bf16 ] && k=k_eval_t16
   timeout -s KILL 120 rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$out/f_$dt" -- python3 tools/kernel_only.py $dt 30 > "$out/f_$dt.log" 2>&1
   timeout -s KILL 120 rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$out/w_$dt" -- python3 tools/kernel_only.py $dt 30 > "$out/w_$dt.log" 2>&1

@@ -12,6 +12,7 @@ run d4_b2048_t1  --depth 4 --batch 2048 --dtype bf16 --threads 1
 run d4_b2048_t12 --depth 4 --batch 2048 --dtype bf16 --threads 12
 run d4_b2048_t12_f32 --depth 4 --batch 2048 --dtype f32 --threads 12
 run d4_b2048_t12_f32s --depth 4 --batch 2048 --dtype f32s --threads 12
+run d4_b2048_t12_f32s3 --depth 4 --batch 2048 --dtype f32s3 --threads 12
 run d5_b2048_t12 --depth 5 --batch 2048 --dtype bf16 --threads 12
 run d5_b8192_t1  --depth 5 --batch 8192 --dtype bf16 --threads 1
 run d5_b8192_t6 --depth 5 --batch 8192 --dtype bf16 --threads 6

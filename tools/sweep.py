@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--dtypes", default="bf16,f32,f32s")
+    ap.add_argument("--dtypes", default="bf16,f32,f32s,f32s3")
     ap.add_argument("--reps", type=int, default=15)
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
