@@ -63,6 +63,7 @@ SIGNATURES = {
     "bf_host_encode_wire": (_int, [_vp, _sz, _vp, _sz, _vp, _vp, _c.POINTER(_sz), _c.POINTER(_sz)]),
     "bf_packed_floats": (_sz, []),
     "bf_pack_weights": (_int, [_vp, _sz, _vp, _sz]),
+    "bf_pack_weights_ex": (_int, [_vp, _sz, _vp, _sz, _int]),
     "bf_pack_policy_weights": (_int, [_vp, _sz, _vp, _sz]),
     "bf_ctx_set_policy": (_int, [_vp, _vp, _sz]),
     "bf_policy_features_wire": (_int, [_vp, _vp, _sz, _vp, _sz, _vp, _vp]),

@@ -63,10 +63,10 @@ constexpr int kStreamGroups = kInputGroups + kC2Tiles * kPerC2Groups + kConv4Gro
 // BF_PRECISION_F32_SPLIT: the same input and 1x1 sections (other contents, pack.cpp); a 3x3 chunk is 9 taps x 2 k-steps
 // of 16 channels x 3 bf16 terms of the kernels, one group (one v_mfma_f32_32x32x16_bf16 A fragment) each
 constexpr int kConvSplitChunkGroups = 9 * 2 * 3;           // 54
-constexpr int kStreamGroupsSplit = kInputGroups + kC2Tiles * kPerC2Groups + 10 * kConvSplitChunkGroups;  // 1516
+constexpr int kStreamGroupsSplit = kInputGroups + kC2Tiles * kPerC2Groups + 9 * kConvSplitChunkGroups;  // 1462 (4 + 5 chunks)
 // BF_PRECISION_F32_SPLIT3: the pair with three terms a side too: 15 + 8 k-steps of 16, three kernel terms each
 constexpr int kPerC2GroupsSplit3 = (15 + 8) * 3;           // 69
-constexpr int kStreamGroupsSplit3 = kInputGroups + kC2Tiles * kPerC2GroupsSplit3 + 10 * kConvSplitChunkGroups;  // 1884
+constexpr int kStreamGroupsSplit3 = kInputGroups + kC2Tiles * kPerC2GroupsSplit3 + 9 * kConvSplitChunkGroups;  // 1830
 constexpr int kStreamChunk = 8;       // groups a workgroup walks between two barriers (eval_f32.hip)
 constexpr int kStreamPadGroups = 32;  // prefetch runs up to three chunks past the end
 // one image size for all three precisions (the shorter streams leave the tail of the region unused)

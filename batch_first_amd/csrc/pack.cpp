@@ -273,12 +273,19 @@ extern "C" int bf_pack_policy_weights(const float* h_weights, size_t n_floats, f
     return BF_OK;
 }
 
-extern "C" int bf_pack_weights(const float* h_weights, size_t n_floats, float* h_packed, size_t n_packed) {
+extern "C" int bf_pack_weights_ex(const float* h_weights, size_t n_floats, float* h_packed, size_t n_packed, int precision) {
     if (!h_weights || !h_packed) return bf::fail(BF_E_ARG, "bf_pack_weights: null pointer");
     if (n_floats != bf::kWeightFloats)
         return bf::fail(BF_E_ARG, "bf_pack_weights: expected %zu weight floats, got %zu", bf::kWeightFloats, n_floats);
     if (n_packed != bf::kPackedFloats)
         return bf::fail(BF_E_ARG, "bf_pack_weights: expected room for %zu packed floats, got %zu", bf::kPackedFloats, n_packed);
-    bf::pack_weights(h_weights, h_packed, false, false);
+    if (precision != BF_PRECISION_F32 && precision != BF_PRECISION_F32_SPLIT && precision != BF_PRECISION_F32_SPLIT3)
+        return bf::fail(BF_E_ARG, "bf_pack_weights_ex: precision %d has no image of this kind", precision);
+    bf::pack_weights(h_weights, h_packed, false,
+                     precision == BF_PRECISION_F32_SPLIT ? 1 : precision == BF_PRECISION_F32_SPLIT3 ? 2 : 0);
     return BF_OK;
+}
+
+extern "C" int bf_pack_weights(const float* h_weights, size_t n_floats, float* h_packed, size_t n_packed) {
+    return bf_pack_weights_ex(h_weights, n_floats, h_packed, n_packed, BF_PRECISION_F32);
 }

@@ -244,7 +244,7 @@ def main():
     # BF_PRECISION_F32_SPLIT beside them (round 3): the fp32 kernel's structure with the 1x1 pair and the 3x3 layers
     # as sums of bf16 x bf16 products.  No fraction of the fp32 peak (it executes no fp32 MFMA); the block gives
     # boards/s, the kernel time beside k_eval_f32's, and the bf16 MFMA work the kernel EXECUTES per board (2 waves x
-    # (240 + 16 x 92 + 10 x 108) v_mfma_f32_32x32x16_bf16 of 32 768 FLOP: 5.2 x the algorithmic FLOPs, that is the
+    # (240 + 16 x 92 + 9 x 108) v_mfma_f32_32x32x16_bf16 of 32 768 FLOP: 5.0 x the algorithmic FLOPs, that is the
     # price of the terms) against the bf16 peak
     def split_block(dtype, code, mfma_per_wave, what):
         s_elapsed, s_kernel_ms, _, s_ctx = measure(dtype)
@@ -270,10 +270,10 @@ def main():
 
     split = split3 = None
     if not bf16:
-        split = split_block("f32s", "BF_PRECISION_F32_SPLIT", 240 + 16 * 92 + 10 * 108,
+        split = split_block("f32s", "BF_PRECISION_F32_SPLIT", 240 + 16 * 92 + 9 * 108,
                             "236->512->128 pair as (hi+mid) x (hi+mid) bf16, six 3x3 layers as (hi+mid+lo) x (hi+mid+lo) "
                             "bf16 (six products)")
-        split3 = split_block("f32s3", "BF_PRECISION_F32_SPLIT3", 240 + 16 * 138 + 10 * 108,
+        split3 = split_block("f32s3", "BF_PRECISION_F32_SPLIT3", 240 + 16 * 138 + 9 * 108,
                              "236->512->128 pair and six 3x3 layers as (hi+mid+lo) x (hi+mid+lo) bf16 (six products): every "
                              "matrix product at 24 significant bits, scores as close to the oracle as the fp32 kernel's")
     if shard:

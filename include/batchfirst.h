@@ -306,6 +306,10 @@ int bf_host_split_wire(const uint64_t* h_occupied_bbs, size_t n, size_t n_parts,
  * (bf_ctx_create uploads exactly this).  Exposed so the arrangement can be checked on a CPU. */
 size_t bf_packed_floats(void);
 int bf_pack_weights(const float* h_weights, size_t n_floats, float* h_packed, size_t n_packed);
+/* The image a context of the given precision uploads: BF_PRECISION_F32 (= bf_pack_weights), BF_PRECISION_F32_SPLIT or
+ * BF_PRECISION_F32_SPLIT3 (the same size, the 1x1 pair and the 3x3 layers as bf16 terms; tests/kernel_sim.py walks
+ * all three on a CPU).  BF_PRECISION_BF16 has an image of its own (below) and is refused here. */
+int bf_pack_weights_ex(const float* h_weights, size_t n_floats, float* h_packed, size_t n_packed, int precision);
 
 int bf_pack_policy_weights(const float* h_weights, size_t n_floats, float* h_packed, size_t n_packed);
 

@@ -1,17 +1,20 @@
 """Lane-level NumPy model of k_eval_f32 (batch_first_amd/csrc/eval_f32.hip).
 
-It walks the packed weight image (bf_pack_weights) exactly as one workgroup does -- same
-k-step order, same register/lane maps for v_mfma_f32_32x32x2_f32 -- so the fragment
+It walks the packed weight image (bf_pack_weights / bf_pack_weights_ex) exactly as one workgroup does -- same
+k-step order, same register/lane maps for v_mfma_f32_32x32x2_f32 and v_mfma_f32_32x32x16_bf16 -- so the fragment
 arrangement and the chaining of accumulator tiles can be checked against the oracle on a CPU,
-without a GPU.  Test infrastructure only.
+without a GPU.  split = 0: float32; 1: BF_PRECISION_F32_SPLIT (two bf16 terms a side in the 1x1 pair, three in the
+3x3 layers); 2: BF_PRECISION_F32_SPLIT3 (three everywhere).  Sums are float64 here, so what is modelled of the split
+precisions is the operand terms and which of their products are taken, not the kernel's float32 rounding.
+Test infrastructure only.
 """
 import numpy as np
 
 INPUT_CONVS = [(3, 1, 1, 64, 0, 2), (3, 2, 2, 32, 64, 1), (3, 3, 3, 20, 96, 1), (3, 4, 4, 20, 116, 1),
                (3, 5, 5, 18, 136, 1), (3, 6, 6, 18, 154, 1), (3, 7, 7, 16, 172, 1), (2, 2, 4, 24, 188, 1),
                (2, 4, 2, 24, 212, 1)]
-STREAM_GROUPS = 1300
-STREAM_REGION = 1884 + 32   # groups the image reserves: the longest stream (bf_layout.h: kStreamGroupsSplit3) + padding
+STREAM_GROUPS = {0: 1300, 1: 1462, 2: 1830}   # bf_layout.h: kStreamGroups, kStreamGroupsSplit, kStreamGroupsSplit3
+STREAM_REGION = 1830 + 32   # groups the image reserves: the longest stream (bf_layout.h: kStreamGroupsSplit3) + padding
 BIAS_FLOATS = 1104
 B_X1, B_X2, B_X3, B_X4, B_X10, B_LOGIT = 0, 236, 748, 876, 1068, 1084
 
@@ -50,6 +53,29 @@ def mfma(a, b, acc):
         acc[t] += D[rowmap(t, HL), LN]
 
 
+def bf16_terms(x, n):
+    """x (float64 holding float32 values) as n bf16 terms, each round-to-nearest-even of what is left (split2 / split3
+    in the kernel, split_bf16x3 in pack.cpp).  Returns n float64 arrays."""
+    r = np.asarray(x, np.float64).astype(np.float32)
+    out = []
+    for _ in range(n):
+        u = r.view(np.uint32).astype(np.uint64)
+        u = (u + 0x7FFF + ((u >> 16) & 1)) >> 16
+        t = (u.astype(np.uint32) << 16).view(np.float32)
+        out.append(t.astype(np.float64))
+        r = (r - t).astype(np.float32)
+    return out
+
+
+def split_products(w_terms, x_terms, acc, fragment):
+    """acc += sum of the products the kernel takes: all of them for two terms a side, those with i + j <= 2 for
+    three.  fragment(term) -> b8[64 lanes][8]."""
+    for i, w in enumerate(w_terms):
+        for j in range(len(x_terms)):
+            if len(w_terms) == 2 or i + j <= 2:
+                mfma_bf16(w, fragment(x_terms[j]), acc)
+
+
 class Stream:
     def __init__(self, packed):
         self.data = packed[:STREAM_REGION * 256].reshape(-1, 64, 4)
@@ -72,7 +98,7 @@ class Stream:
         self.kstep += n
 
 
-def eval_board(packed, mailbox64):
+def eval_board(packed, mailbox64, split=0):
     """mailbox64: uint8[64] codes (15 = empty) in the mover's frame.  Returns (score, intermediates)."""
     packed = np.asarray(packed, np.float32)
     bias = packed[STREAM_REGION * 256:][:BIAS_FLOATS].astype(np.float64)
@@ -114,7 +140,23 @@ def eval_board(packed, mailbox64):
         for c3 in range(4):
             for t in range(16):
                 acc3[c3, t] = bias[B_X3 + 32 * c3 + rowmap(t, HL)]
-        for c2 in range(16):
+        pair_terms = {0: 0, 1: 2, 2: 3}[split]
+        if split:
+            xp = np.zeros((120, 64))
+            xp[:118] = x1
+            xp[118] = np.where(HL == 0, 1.0, 0.0)        # the all-ones slot that carries the hidden layer's shift
+            xt = bf16_terms(xp, pair_terms)
+        for c2 in range(16 if split else 0):
+            acc2 = np.zeros((16, 64))
+            for s in range(15):          # k-step s: registers 8s .. 8s+7 of the lane
+                wt = [ws.next_group_bf16() for _ in range(pair_terms)]
+                split_products(wt, xt, acc2, lambda x: x[8 * s:8 * s + 8].T)
+            ht = bf16_terms(np.maximum(acc2, 0), pair_terms)
+            for c3 in range(4):
+                for v in range(2):
+                    wt = [ws.next_group_bf16() for _ in range(pair_terms)]
+                    split_products(wt, ht, acc3[c3], lambda x: x[8 * v:8 * v + 8].T)
+        for c2 in range(0 if split else 16):
             acc2 = np.zeros((16, 64))
             for r in range(118):
                 mfma(ws.next(), x1[r], acc2)
@@ -146,6 +188,15 @@ def eval_board(packed, mailbox64):
     def conv_chunk(ws, xplane, acc, half):
         sq = 32 * half + LN
         rank, file = sq >> 3, sq & 7
+        if split:   # three terms a side; k-step s, element (h, j) = channel rowmap(8 h + j, s)
+            xt = bf16_terms(xplane, 3)
+            for tap in range(9):
+                dr, df = tap // 3 - 1, tap % 3 - 1
+                for s in range(2):
+                    wt = [ws.next_group_bf16() for _ in range(3)]
+                    chan = rowmap(8 * HL[:, None] + np.arange(8)[None, :], s)      # [64 lanes][8]
+                    split_products(wt, xt, acc, lambda x: x[chan, (rank + 1 + dr)[:, None], (file + 1 + df)[:, None]])
+            return
         for tap in range(9):
             dr, df = tap // 3 - 1, tap % 3 - 1
             for s in range(16):
@@ -188,5 +239,5 @@ def eval_board(packed, mailbox64):
     s = part.sum(axis=0)
     y = np.maximum(s + bias[B_X10:B_X10 + 16], 0)
     inter["x10"] = y
-    assert streams[0].kstep == STREAM_GROUPS * 4
+    assert streams[0].kstep == streams[1].kstep == STREAM_GROUPS[split] * 4, (streams[0].kstep, streams[1].kstep)
     return float((y * bias[B_LOGIT:B_LOGIT + 16]).sum()), inter

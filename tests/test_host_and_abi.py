@@ -81,17 +81,26 @@ def test_start_board_evaluations_with_plain_callable():
     assert scores.dtype == np.float32 and np.array_equal(scores, exp.astype(np.float32))
 
 
-def test_packed_image_drives_kernel_model_to_oracle_scores(golden):
-    """Walks the fragment stream the way the HIP kernel does (tests/kernel_sim.py)."""
+@pytest.mark.parametrize("dtype,split,tol", [("f32", 0, 1e-5), ("f32s", 1, 5e-5), ("f32s3", 2, 1e-5)])
+def test_packed_image_drives_kernel_model_to_oracle_scores(golden, dtype, split, tol):
+    """Walks the fragment stream the way the HIP kernel does (tests/kernel_sim.py), for each of the three precisions
+    that share the kernel: the float32 image, and the images whose 1x1 pair and 3x3 layers are bf16 terms
+    (BF_PRECISION_F32_SPLIT, BF_PRECISION_F32_SPLIT3; the kernel's operand splits and product selection are modelled,
+    its float32 sums are float64 here)."""
     lib = _lib.load()
     w = W.make_weights(seed=1234, bn="perturbed")
     blob = W.to_blob(w)
     packed = np.zeros(lib.bf_packed_floats(), np.float32)
-    _lib.check(lib.bf_pack_weights(blob.ctypes.data, blob.size, packed.ctypes.data, packed.size))
+    _lib.check(lib.bf_pack_weights_ex(blob.ctypes.data, blob.size, packed.ctypes.data, packed.size, _lib.precision_code(dtype)))
+    if split == 0:
+        again = np.zeros_like(packed)
+        _lib.check(lib.bf_pack_weights(blob.ctypes.data, blob.size, again.ctypes.data, again.size))
+        assert np.array_equal(packed.view(np.uint32), again.view(np.uint32))
     for b in (1, 7, 500):
-        score, inter = kernel_sim.eval_board(packed, golden["mailbox"][b])
+        score, inter = kernel_sim.eval_board(packed, golden["mailbox"][b], split)
         ref = golden["scores_f64_perturbed"][b]
-        assert abs(score - ref) <= 1e-5 * max(abs(ref), 0.2), b
+        assert abs(score - ref) <= tol * max(abs(ref), 0.2), (b, score, ref)
+    assert lib.bf_pack_weights_ex(blob.ctypes.data, blob.size, packed.ctypes.data, packed.size, _lib.BF_PRECISION_BF16) == _lib.BF_E_ARG
 
 
 def test_weights_blob_round_trip():
