@@ -73,7 +73,7 @@ constexpr int SLOTS = 3;
 constexpr int SPLIT_SLOTS = BF_F32_SPLIT_SLOTS;
 // SPLIT level 2 (BF_PRECISION_F32_SPLIT3) keeps the third term of x1 in LDS (60 KB a workgroup), so its ring has
 // chunks of 4 groups: 12 KB, two workgroups a CU as for the other two forms.
-constexpr int chunk_of(int split) { return split == 2 ? 4 : CHUNK; }
+constexpr int chunk_of(int split) { return split == 2 && BPB == 2 ? 4 : CHUNK; }   // (BF_BPB = 4 experiments: one workgroup a CU, room for the full ring)
 constexpr int slots_of(int split) { return split ? SPLIT_SLOTS : SLOTS; }
 #ifndef BF_F32_LA
 #define BF_F32_LA 3
@@ -87,7 +87,7 @@ constexpr int C2_UNROLL = 4;           // hidden tiles per loop body: 4 * 46 gro
 static_assert(CHUNK % WAVES == 0 && chunk_of(2) % WAVES == 0, "every wave fetches whole groups");
 static_assert(kInputGroups % CHUNK == 0, "the tile loop must start on a chunk boundary");
 static_assert((kPerC2Groups * C2_UNROLL) % CHUNK == 0, "loop body must be whole chunks");
-static_assert((kPerC2GroupsSplit3 * C2_UNROLL) % chunk_of(2) == 0, "loop body must be whole chunks");
+static_assert(BPB != 2 || (kPerC2GroupsSplit3 * C2_UNROLL) % chunk_of(2) == 0, "loop body must be whole chunks");
 static_assert(kC2Tiles % C2_UNROLL == 0, "");
 static_assert(kStreamPadGroups >= SPLIT_SLOTS * CHUNK + LA && kStreamPadGroups >= 3 * CHUNK + LA, "prefetch overrun must stay inside the image");
 
@@ -375,7 +375,7 @@ __device__ __forceinline__ void conv3x3_chunk_split(WStream& ws, int g0, const c
 // hidden tile, other contents: pack.cpp); and the six 3x3 layers with both operands as THREE bf16 terms
 // (conv3x3_chunk_split).  Stage 1 and the head are this kernel unchanged.
 template <int MODE, int SPLIT>
-__global__ __launch_bounds__(THREADS, 2) void k_eval_f32(const uint8_t* __restrict__ mailbox, unsigned n_boards,
+__global__ __launch_bounds__(THREADS, 4 / BPB) void k_eval_f32(const uint8_t* __restrict__ mailbox, unsigned n_boards,
                                                           const f32x4* __restrict__ wstream,
                                                           const float* __restrict__ bias,
                                                           const f32x4* __restrict__ headw,

@@ -31,6 +31,8 @@ def main():
     from oracle import encoding
 
     blob = weights.to_blob(weights.make_weights(seed=1234, bn="perturbed"))
+    if os.environ.get("BF_ZERO_WEIGHTS"):   # diagnostic: data-dependent power (operand toggling) against the same instruction stream
+        blob = np.zeros_like(blob)
     structs = positions.random_structs(args.n, seed=5)
     nib, occ = None, None
     # mailbox via the first library's own encoder
