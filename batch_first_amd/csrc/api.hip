@@ -61,6 +61,7 @@ struct bf_ctx : Lane {               // the base is the value network's lane
     int device = 0;
     uint8_t* d_static_mailbox = nullptr;  // this device's copy of `scratch` (bf_eval_structs_noalloc)
     int precision = BF_PRECISION_F32;
+    int cu_count = 0;                     // compute units of the device (k_eval_f32q's limit: one board a unit)
     // BF_T16_TWO_KERNELS=1 at creation: records always go through k_to_mailbox first (A/B and the equality test);
     // otherwise the 16x16x32 kernel decodes 4-byte-aligned records itself (one launch a call)
     bool two_kernels = false;
@@ -154,10 +155,24 @@ bool use_split(const bf_ctx* c, size_t n) {
     return c->precision == BF_PRECISION_BF16 && n <= g_split_boards.load(std::memory_order_relaxed);
 }
 
+// A float32 context runs calls of up to this many boards on k_eval_f32q (one board per workgroup, eight waves; the same
+// bits as k_eval_f32: eval_f32q.hip).  Its 132 KB of LDS allow one workgroup per compute unit, so beyond one board
+// per unit it runs in rounds and k_eval_f32 is as fast: the limit is the device's unit count, at most
+// BF_F32Q_BOARDS (environment, default 256; 0 turns the kernel off).
+size_t f32q_boards(const bf_ctx* c) {
+    static const size_t cap = [] {
+        const char* e = std::getenv("BF_F32Q_BOARDS");
+        return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)256;
+    }();
+    return std::min(cap, (size_t)c->cu_count);
+}
+bool use_f32q(const bf_ctx* c, size_t n) { return c->precision == BF_PRECISION_F32 && n <= f32q_boards(c); }
+
 // The value network in the context's precision.
 hipError_t launch_eval(bf_ctx* c, const uint8_t* d_mailbox, size_t n, float* d_scores, float* d_debug, hipStream_t s) {
     if (!d_debug && use_split(c, n))
         return bf::launch_eval_t16_split(d_mailbox, bf::kMailboxBytes, false, n, c->d_image16, d_scores, s);
+    if (!d_debug && use_f32q(c, n)) return bf::launch_eval_f32q(d_mailbox, n, c->d_packed, d_scores, s);
     if (c->precision == BF_PRECISION_BF16)
         return bf::launch_eval_t16(d_mailbox, n, c->d_image16, d_scores, d_debug, s);
     return bf::launch_eval_f32(d_mailbox, n, c->d_packed, d_scores, d_debug, s, split_level(c->precision));
@@ -362,6 +377,7 @@ extern "C" int bf_ctx_create_ex(bf_ctx** out, int device, const float* h_weights
     if (!c) return bf::fail(BF_E_ARG, "bf_ctx_create: out of host memory");
     c->device = device;
     c->precision = precision;
+    if (hipDeviceGetAttribute(&c->cu_count, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) c->cu_count = 0;
     auto bail = [&](int code) {
         bf_ctx_destroy(c);
         return code;
@@ -828,6 +844,7 @@ hipError_t launch_policy_features(bf_ctx* c, const uint8_t* d_mailbox, size_t n,
         return bf::launch_policy_features_t16_split(d_mailbox, bf::kMailboxBytes, false, n, c->d_policy_image16, d_x9, s);
     if (c->precision == BF_PRECISION_BF16)
         return bf::launch_policy_features_t16(d_mailbox, n, c->d_policy_image16, d_x9, s);
+    if (use_f32q(c, n)) return bf::launch_policy_features_f32q(d_mailbox, n, c->d_policy_packed, d_x9, s);
     return bf::launch_policy_features_f32(d_mailbox, n, c->d_policy_packed, d_x9, s, split_level(c->precision));
 }
 

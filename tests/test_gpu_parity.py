@@ -453,3 +453,49 @@ def test_f32_split_precision_scores_within_the_fp32_bound(torch_mod, golden, dty
         assert e3 < x3_bar                                             # two layers of 16-bit (f32s) / 24-bit operands
     finally:
         ctx.close()
+
+
+def test_fp32_small_calls_run_another_kernel_with_the_same_bits(torch_mod, golden):
+    """A float32 context runs calls of up to 256 boards on k_eval_f32q (one board per workgroup, eight waves, 16 x 16
+    tiles for the 3x3 layers: eval_f32q.hip) and larger ones on k_eval_f32.  Both fp32 MFMA shapes are fmaf chains in k
+    order (tools/mfma_shape_bits.hip) and the small kernel keeps every layer's order of k, so a board's score and the
+    move-scoring network's features must not depend on the size of the call it travels in: bit equality over call
+    sizes around every switch, for mailbox, record and wire input, value network and move-scoring features
+    (as test_gpu_bf16.py does for k_eval_t16s)."""
+    from batch_first_amd import ops
+    w = W.make_weights(seed=1234, bn="perturbed")
+    ctx = ops.DeviceContext(w, device=0)
+    try:
+        ctx.set_policy(W.make_policy_weights(seed=4321))
+        recs = torch_mod.from_numpy(golden["records"].copy()).cuda()
+        mbc = golden["mailbox"]
+        mb = torch_mod.from_numpy((mbc[:, 0::2] | (mbc[:, 1::2] << 4)).astype(np.uint8)).cuda()
+        big = torch_mod.ops.batchfirst.eval_structs(ctx.handle, recs)              # 1 024 boards: k_eval_f32
+        big_mb = torch_mod.ops.batchfirst.eval_mailbox(ctx.handle, mb)
+        big_x9 = torch_mod.ops.batchfirst.policy_features_structs(ctx.handle, recs)
+        assert torch_mod.equal(big, big_mb)
+        ok, worst = _score_ok(big.cpu().numpy(), golden["scores_f32_perturbed"])
+        assert ok
+        for n, lo in ((1, 0), (1, 777), (2, 5), (63, 100), (64, 200), (200, 300), (255, 512), (256, 768), (257, 3), (300, 700)):
+            part = torch_mod.ops.batchfirst.eval_structs(ctx.handle, recs[lo:lo + n].contiguous())
+            assert torch_mod.equal(part, big[lo:lo + n]), ("records", n, lo)
+            part = torch_mod.ops.batchfirst.eval_mailbox(ctx.handle, mb[lo:lo + n].contiguous())
+            assert torch_mod.equal(part, big[lo:lo + n]), ("mailbox", n, lo)
+            x9 = torch_mod.ops.batchfirst.policy_features_structs(ctx.handle, recs[lo:lo + n].contiguous())
+            assert torch_mod.equal(x9, big_x9[lo:lo + n]), ("features", n, lo)
+    finally:
+        ctx.close()
+    # the reference's callable (wire format, host arrays) at a small and a large size
+    from batch_first_amd import chestimator
+    bp, _, closer = chestimator.get_inference_functions(W.to_blob(w))
+    try:
+        structs = np.frombuffer(golden["records"].tobytes(), dtype=P.COMPACT_DTYPE)
+        whole = bp(golden["piece_filters"], golden["occupied_bbs"])
+        assert np.array_equal(whole.view(np.uint32), big.cpu().numpy().view(np.uint32))
+        nib, occ = E.struct_array_to_ann_inputs(structs[40:190])
+        small = bp(nib, occ)
+        assert np.array_equal(small.view(np.uint32), whole[40:190].view(np.uint32))
+        small = bp.eval_structs(structs[900:1000])
+        assert np.array_equal(small.view(np.uint32), whole[900:1000].view(np.uint32))
+    finally:
+        closer()

@@ -16,7 +16,7 @@ python3 "$root/tools/isa_hazards.py" $src-hip-amdgcn-amd-amdhsa-gfx950.s
 grep "vgpr_spill_count\|\.vgpr_count\|\.agpr_count" $src-hip-amdgcn-amd-amdhsa-gfx950.s | head -9 || true
 cd "$root/batch_first_amd/csrc"
 objs=""
-for o in api encode eval_f32 eval_t16 eval_t16s pack pack_t16 host_encode; do
+for o in api encode eval_f32 eval_f32q eval_t16 eval_t16s pack pack_t16 host_encode; do
     if [ "$o" = "$src" ]; then objs="$objs $obj/$o.o"; else objs="$objs $o.o"; fi
 done
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $objs -o "$root/build/variants/libbf_$name.so"
