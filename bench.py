@@ -163,6 +163,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    side_warmup = args.warmup if shard else max(args.warmup, SIDE_WARMUP)   # (a 2^24-board step is long enough as it is)
+
     def measure(dtype):
         """The timed region of the contract (W warm-up steps, exactly K steps between fences, MAX over
         ranks) and then the dominant kernel alone, for one precision.  Returns (elapsed seconds of the K
@@ -182,7 +184,7 @@ def main():
         # uploading their weights) during which the GPU idles and drops its clock; their timed region is short (20 steps
         # of 1.7 ms for bf16), so three warm-up steps left one run in ten timing the clock's ramp (profiles/r3/README.md).
         # They get at least SIDE_WARMUP untimed steps, and say so in their "warmup" field.  The headline keeps W.
-        for _ in range(args.warmup if dtype == args.dtype else max(args.warmup, SIDE_WARMUP)):
+        for _ in range(args.warmup if dtype == args.dtype else side_warmup):
             step()
         fence()
         t0 = time.perf_counter()
@@ -236,7 +238,7 @@ def main():
         o_elapsed, o_kernel_ms, o_mailbox_ms, o_ctx = measure("bf16")
         o_tflops = spec.FLOPS_PER_BOARD * n_kernel / (o_kernel_ms * 1e-3) / 1e12
         o_traffic, o_src, o_match = profiled_traffic("bf16")
-        other = {"value": total_boards * args.steps / o_elapsed, "unit": "boards/s", "steps": args.steps, "warmup": max(args.warmup, SIDE_WARMUP),
+        other = {"value": total_boards * args.steps / o_elapsed, "unit": "boards/s", "steps": args.steps, "warmup": side_warmup,
                  "ms_per_step": 1e3 * o_elapsed / args.steps, "dtype": "bf16",
                  "config": {"workload": "BASELINE configs[2] kernel (bf16 operands, fp32 sums) on the headline's records and batch"},
                  "roofline": {"bound": "mfma", "kernel": BF16_KERNEL + "<4> (node records in: the kernel the timed step launches)",
@@ -256,7 +258,7 @@ def main():
         mfma_per_board = 2 * mfma_per_wave
         executed = mfma_per_board * 32768
         s_tflops = executed * n_kernel / (s_kernel_ms * 1e-3) / 1e12
-        block = {"value": total_boards * args.steps / s_elapsed, "unit": "boards/s", "steps": args.steps, "warmup": max(args.warmup, SIDE_WARMUP),
+        block = {"value": total_boards * args.steps / s_elapsed, "unit": "boards/s", "steps": args.steps, "warmup": side_warmup,
                  "ms_per_step": 1e3 * s_elapsed / args.steps, "dtype": dtype,
                  "config": {"workload": code + " on the headline's records and batch: " + what + ", fp32 sums, stage 1 and "
                                         "head as the fp32 kernel (scores within the fp32 kernel's 1e-4 bound, "
