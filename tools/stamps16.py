@@ -1,4 +1,6 @@
-"""Reads per-wave stage stamps from a BF_STAMPS build of the bf16 kernel (diagnostic only).
+"""Reads per-wave stage stamps from a BF_STAMPS build of the round-1 bf16 kernel k_eval_bf16 (diagnostic only; that kernel
+was removed in round 3 -- kept as the record of how the stamps under profiles/r1 were taken; tools/stamps_t16.py is its
+successor for k_eval_t16).
     python tools/stamps16.py build/variants/libbf_x.so 65536 [boards per workgroup]"""
 import ctypes, os, sys
 import numpy as np
