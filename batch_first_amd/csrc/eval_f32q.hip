@@ -175,7 +175,7 @@ __device__ __forceinline__ void conv3x3_chunk_q(const f32x4* wb, int hi, const f
             b[(2 * j + 1) % (2 * BD)] = xb[b_off(2 * (j + BD) + 1)];
 #endif
         }
-        __builtin_amdgcn_sched_barrier(0);   // the reads stay ahead of their use
+        __builtin_amdgcn_sched_barrier(0);   // the reads stay ahead of their use (2, 4 or 8 pairs ahead, pinned or not: the same time)
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hi ? av.y : av.x, b0, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hi ? av.w : av.z, b1, acc, 0, 0, 0);
     }
