@@ -155,7 +155,7 @@ bool use_split(const bf_ctx* c, size_t n) {
     return c->precision == BF_PRECISION_BF16 && n <= g_split_boards.load(std::memory_order_relaxed);
 }
 
-// A float32 context runs calls of up to this many boards on k_eval_f32q (one board per workgroup, eight waves; the same
+// A float32 (or split-precision) context runs calls of up to this many boards on k_eval_f32q (one board per workgroup, eight waves; the same
 // bits as k_eval_f32: eval_f32q.hip).  Its 132 KB of LDS allow one workgroup per compute unit, so beyond one board
 // per unit it runs in rounds and k_eval_f32 is as fast: the limit is the device's unit count, at most
 // BF_F32Q_BOARDS (environment, default 256; 0 turns the kernel off).
@@ -166,13 +166,13 @@ size_t f32q_boards(const bf_ctx* c) {
     }();
     return std::min(cap, (size_t)c->cu_count);
 }
-bool use_f32q(const bf_ctx* c, size_t n) { return c->precision == BF_PRECISION_F32 && n <= f32q_boards(c); }
+bool use_f32q(const bf_ctx* c, size_t n) { return c->precision != BF_PRECISION_BF16 && n <= f32q_boards(c); }
 
 // The value network in the context's precision.
 hipError_t launch_eval(bf_ctx* c, const uint8_t* d_mailbox, size_t n, float* d_scores, float* d_debug, hipStream_t s) {
     if (!d_debug && use_split(c, n))
         return bf::launch_eval_t16_split(d_mailbox, bf::kMailboxBytes, false, n, c->d_image16, d_scores, s);
-    if (!d_debug && use_f32q(c, n)) return bf::launch_eval_f32q(d_mailbox, n, c->d_packed, d_scores, s);
+    if (!d_debug && use_f32q(c, n)) return bf::launch_eval_f32q(d_mailbox, n, c->d_packed, d_scores, s, split_level(c->precision));
     if (c->precision == BF_PRECISION_BF16)
         return bf::launch_eval_t16(d_mailbox, n, c->d_image16, d_scores, d_debug, s);
     return bf::launch_eval_f32(d_mailbox, n, c->d_packed, d_scores, d_debug, s, split_level(c->precision));
@@ -844,7 +844,7 @@ hipError_t launch_policy_features(bf_ctx* c, const uint8_t* d_mailbox, size_t n,
         return bf::launch_policy_features_t16_split(d_mailbox, bf::kMailboxBytes, false, n, c->d_policy_image16, d_x9, s);
     if (c->precision == BF_PRECISION_BF16)
         return bf::launch_policy_features_t16(d_mailbox, n, c->d_policy_image16, d_x9, s);
-    if (use_f32q(c, n)) return bf::launch_policy_features_f32q(d_mailbox, n, c->d_policy_packed, d_x9, s);
+    if (use_f32q(c, n)) return bf::launch_policy_features_f32q(d_mailbox, n, c->d_policy_packed, d_x9, s, split_level(c->precision));
     return bf::launch_policy_features_f32(d_mailbox, n, c->d_policy_packed, d_x9, s, split_level(c->precision));
 }
 

@@ -41,9 +41,11 @@ hipError_t launch_eval_f32(const uint8_t* d_mailbox, size_t n, const float* d_pa
 hipError_t launch_policy_features_f32(const uint8_t* d_mailbox, size_t n, const float* d_packed, float* d_x9,
                                       hipStream_t stream, int split = 0);
 // The same two for small calls: one board per workgroup, eight waves, scores and features bit-identical to the two
-// above at split = 0 (eval_f32q.hip).  Float32 image only.
-hipError_t launch_eval_f32q(const uint8_t* d_mailbox, size_t n, const float* d_packed, float* d_scores, hipStream_t stream);
-hipError_t launch_policy_features_f32q(const uint8_t* d_mailbox, size_t n, const float* d_packed, float* d_x9, hipStream_t stream);
+// above at the same split level (eval_f32q.hip).
+hipError_t launch_eval_f32q(const uint8_t* d_mailbox, size_t n, const float* d_packed, float* d_scores, hipStream_t stream,
+                            int split = 0);
+hipError_t launch_policy_features_f32q(const uint8_t* d_mailbox, size_t n, const float* d_packed, float* d_x9, hipStream_t stream,
+                                       int split = 0);
 // d_logit_w: the logit kernel as float32 [73][32] (both images keep it at their head offset)
 hipError_t launch_policy_scores(const float* d_x9, const float* d_logit_w, const unsigned* d_board_index,
                                 const uint8_t* d_from, const uint8_t* d_filter, size_t n_moves, size_t n_boards,

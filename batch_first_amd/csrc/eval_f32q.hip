@@ -22,7 +22,9 @@
 // The 1x1 pair's weights come straight from L2 through a register prefetch ring (every wave needs other groups: no
 // sharing to be had; a few hundred workgroups at most).  One board's fp32 matrix work is 135 k cycles on the four
 // SIMDs of a CU whatever the split, 56 us at 2.4 GHz: that, not 60 us a call, is the floor.
-// Measured: 100-103 us a call for 1 .. 256 boards against 154-158 us on k_eval_f32 (wave life 190 k cycles: stage 1
+// LEVEL 1 / 2 (BF_PRECISION_F32_SPLIT / _SPLIT3) take the same route with the large-batch kernel's bf16-term MFMAs per
+// tile; see the kernel's comment.  Measured: f32s 62-65 us (87 on k_eval_f32<., 1>), f32s3 70-75 us (108).
+// Measured (LEVEL 0): 100-103 us a call for 1 .. 256 boards against 154-158 us on k_eval_f32 (wave life 190 k cycles: stage 1
 // 14 k, 236->512 70 k, 512->128 37 k, 3x3 layers 67 k; profiles/r3/f32q/).
 #include <hip/hip_runtime.h>
 
@@ -68,6 +70,34 @@ __device__ __forceinline__ float relu(float x) {   // as eval_f32.hip: one integ
 #define BFQ_STAMP(i) ((void)0)
 #endif
 #define BFQ_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#define BFQ_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
+
+// ---- LEVEL 1 / 2: BF_PRECISION_F32_SPLIT / _SPLIT3 (eval_f32.hip: k_eval_f32<MODE, SPLIT>), the same bits ---------------
+// split2 / split3 as there: bf16 terms of a pair of float32 values, packed (a low, b high).
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& mid) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+    const float ra = a - __builtin_bit_cast(float, hi << 16);
+    const float rb = b - __builtin_bit_cast(float, hi & 0xFFFF0000u);
+    mid = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{ra, rb}, bf16x2));
+}
+__device__ __forceinline__ void split3(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+    const float ra = a - __builtin_bit_cast(float, hi << 16);
+    const float rb = b - __builtin_bit_cast(float, hi & 0xFFFF0000u);
+    mid = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{ra, rb}, bf16x2));
+    const float sa = ra - __builtin_bit_cast(float, mid << 16);
+    const float sb = rb - __builtin_bit_cast(float, mid & 0xFFFF0000u);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{sa, sb}, bf16x2));
+}
+// The split precisions' term planes (eval_f32.hip): [term][10 x 10 positions][32 channels] bf16, 64 bytes a position,
+// chunk c of a position at chunk (c + padded rank) & 3.  Six sets here: x3's four chunks, two alternating for x4 .. x8.
+constexpr int XS_POS_BYTES = 64, XS_PLANE_BYTES = XP_PLANE * XS_POS_BYTES, XS_SET_BYTES = 3 * XS_PLANE_BYTES;   // 19 200
+constexpr int XS_SETS = 6, XS_RED_OFF = XS_SETS * XS_SET_BYTES / 4;   // float offset of the head's scratch behind them
+static_assert(XS_RED_OFF + 128 * RED_STRIDE <= HID_FLOATS, "term planes and the head's scratch fit the region");
 
 // Groups of the weight stream in a fixed consumption order, P of them in flight from L2 (an L2 hit takes several
 // hundred cycles: P x the MFMA time a group feeds has to cover it).  OFF(i) -> float4 offset of the i-th group from
@@ -198,8 +228,57 @@ struct ChunkFetch {
     }
 };
 
+// conv3x3_chunk_split of eval_f32.hip (three terms a side, its six products in its order) with the weights from L2;
+// f: the chunk's first group in the wave's conv stream (54 groups a chunk, chunks contiguous).
+template <class WS>
+__device__ __forceinline__ void conv3x3_chunk_split_q(WS& ws, int f, const char* set, const int (&xa)[4], f32x16& acc) {
+    auto load_b = [&](int idx, u32x4 (&b)[3]) {
+        const int tap = idx >> 1, s = idx & 1, tr = tap / 3, tf = tap % 3;
+        const char* p = set + xa[(2 * s + tr) & 3] + (tr * XP_W + tf) * XS_POS_BYTES;
+#pragma unroll
+        for (int term = 0; term < 3; ++term) b[term] = *reinterpret_cast<const u32x4*>(p + term * XS_PLANE_BYTES);
+    };
+    u32x4 b[2][3];
+    load_b(0, b[0]);
+#pragma unroll
+    for (int idx = 0; idx < 18; ++idx) {
+        if (idx + 1 < 18) load_b(idx + 1, b[(idx + 1) & 1]);
+        const f32x4 wh = ws.take(f + 3 * idx), wm = ws.take(f + 3 * idx + 1), wl = ws.take(f + 3 * idx + 2);
+        const u32x4 &xh = b[idx & 1][0], &xm = b[idx & 1][1], &xl = b[idx & 1][2];
+        acc = BFQ_MFMA16(wl, xh, acc);
+        acc = BFQ_MFMA16(wh, xl, acc);
+        acc = BFQ_MFMA16(wm, xm, acc);
+        acc = BFQ_MFMA16(wm, xh, acc);
+        acc = BFQ_MFMA16(wh, xm, acc);
+        acc = BFQ_MFMA16(wh, xh, acc);
+    }
+}
+
+// The products of one k-step of the 1x1 pair in k_eval_f32<., SPLIT>'s order: T = 2 terms a side: all four;
+// T = 3: the six with i + j <= 2.  w[term], x[term]: A and B fragments.
+template <int T>
+__device__ __forceinline__ void pair_products(const f32x4 (&w)[T], const u32x4 (&x)[T], f32x16& acc) {
+    if (T == 2) {
+        acc = BFQ_MFMA16(w[1], x[1], acc);
+        acc = BFQ_MFMA16(w[1], x[0], acc);
+        acc = BFQ_MFMA16(w[0], x[1], acc);
+        acc = BFQ_MFMA16(w[0], x[0], acc);
+    } else {
+        acc = BFQ_MFMA16(w[T - 1], x[0], acc);
+        acc = BFQ_MFMA16(w[0], x[T - 1], acc);
+        acc = BFQ_MFMA16(w[1], x[1], acc);
+        acc = BFQ_MFMA16(w[1], x[0], acc);
+        acc = BFQ_MFMA16(w[0], x[1], acc);
+        acc = BFQ_MFMA16(w[0], x[0], acc);
+    }
+}
+
 // MODE 0: scores; 2: x9 features as float32 [board][32][64] into `scores` (the move-scoring network's first stage).
-template <int MODE>
+// LEVEL 0: float32 (k_eval_f32<., 0>); 1, 2: BF_PRECISION_F32_SPLIT / _SPLIT3 (k_eval_f32<., 1 / 2>): the 1x1 pair split
+// over the waves as for float32, the hidden layer exchanged as float32 and split into its bf16 terms by its readers,
+// the 3x3 layers (there a fifth of the time, on the bf16 pipe) by waves (half, 0) alone on the 32 x 32 tiles of the
+// large-batch kernel, the head by the same two waves from their registers.
+template <int MODE, int LEVEL>
 __global__ __launch_bounds__(QTHREADS, 1) void k_eval_f32q(const uint8_t* __restrict__ mailbox, unsigned n_boards,
                                                            const f32x4* __restrict__ wstream, const float* __restrict__ bias,
                                                            const f32x4* __restrict__ headw, float* __restrict__ scores) {
@@ -250,6 +329,192 @@ __global__ __launch_bounds__(QTHREADS, 1) void k_eval_f32q(const uint8_t* __rest
         __syncthreads();   // the hidden layer overwrites the exchange
     }
 
+    if constexpr (LEVEL > 0) {
+        constexpr int T = LEVEL + 1;                                        // terms a side in the 1x1 pair
+        constexpr int PER = LEVEL == 2 ? kPerC2GroupsSplit3 : kPerC2Groups;  // groups a hidden tile: 69 / 46
+        constexpr int G1 = 15 * T, GP = 2 * T;                              // 236 -> 512 groups a tile; 512 -> 128 groups a (tile, c3)
+        constexpr int PD = LEVEL == 2 ? 7 : 11;                             // a group feeds two 32-cycle MFMAs: deep
+        // x1 as bf16 terms, packed for the B operand (k-step s takes registers 8s .. 8s+7; register 118 of lane half 0
+        // is the all-ones slot that carries the hidden layer's shift)
+        unsigned xs[T][60];
+#pragma unroll
+        for (int d = 0; d < 60; ++d) {
+            const float a = 2 * d < kX1Regs ? x1[2 * d] : (2 * d == kX1Regs ? pick(hl, 1.0f, 0.0f) : 0.0f);
+            const float b = 2 * d + 1 < kX1Regs ? x1[2 * d + 1] : 0.0f;
+            if constexpr (T == 2) split2(a, b, xs[0][d], xs[1][d]);
+            else split3(a, b, xs[0][d], xs[1][d], xs[2][d]);
+        }
+        BFQ_STAMP(1);
+        {   // 236 -> 512: hidden tiles 4m .. 4m+3, ReLU, to LDS as float32 (their readers split them)
+            auto off = [](int i) { return ((i / G1) * PER + i % G1) * 64; };
+            GStream<PD, decltype(off)> ws(wstream + (size_t)(kInputGroups + 4 * m * PER) * 64 + lane, off, 4 * G1);
+            float* hid = lds.region + ((half * 16 + 4 * m) * 16) * 64 + lane;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                f32x16 acc2 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 15; ++k) {
+                    f32x4 w[T];
+                    u32x4 x[T];
+#pragma unroll
+                    for (int term = 0; term < T; ++term) {
+                        w[term] = ws.take(u * G1 + T * k + term);
+                        x[term] = u32x4{xs[term][4 * k], xs[term][4 * k + 1], xs[term][4 * k + 2], xs[term][4 * k + 3]};
+                    }
+                    pair_products<T>(w, x, acc2);
+                }
+#pragma unroll
+                for (int t = 0; t < 16; ++t) hid[(u * 16 + t) * 64] = relu(acc2[t]);
+            }
+        }
+        BFQ_STAMP(2);
+        __syncthreads();
+        BFQ_STAMP(3);
+        // 512 -> 128: output tile m over the sixteen hidden tiles in order
+        f32x16 acc3;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc3[t] = pick(hl, bias[kBiasX3 + 32 * m + rowmap(t, 0)], bias[kBiasX3 + 32 * m + rowmap(t, 1)]);
+        {
+            auto off = [](int i) { return ((i / GP) * PER + i % GP) * 64; };
+            GStream<PD, decltype(off)> ws(wstream + (size_t)(kInputGroups + G1 + m * GP) * 64 + lane, off, 16 * GP);
+            const float* hid = lds.region + (half * 16 * 16) * 64 + lane;
+            float h[2][16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) h[0][t] = hid[t * 64];
+#pragma unroll
+            for (int c2 = 0; c2 < 16; ++c2) {
+                if (c2 + 1 < 16) {
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) h[(c2 + 1) & 1][t] = hid[((c2 + 1) * 16 + t) * 64];
+                }
+                unsigned hs[T][8];
+#pragma unroll
+                for (int d = 0; d < 8; ++d) {
+                    if constexpr (T == 2) split2(h[c2 & 1][2 * d], h[c2 & 1][2 * d + 1], hs[0][d], hs[1][d]);
+                    else split3(h[c2 & 1][2 * d], h[c2 & 1][2 * d + 1], hs[0][d], hs[1][d], hs[2][d]);
+                }
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    f32x4 w[T];
+                    u32x4 x[T];
+#pragma unroll
+                    for (int term = 0; term < T; ++term) {
+                        w[term] = ws.take(c2 * GP + T * v + term);
+                        x[term] = u32x4{hs[term][4 * v], hs[term][4 * v + 1], hs[term][4 * v + 2], hs[term][4 * v + 3]};
+                    }
+                    pair_products<T>(w, x, acc3);
+                }
+            }
+        }
+        BFQ_STAMP(4);
+        __syncthreads();   // nobody reads the hidden layer any more: its space becomes the term planes
+        {
+            f32x4* z = reinterpret_cast<f32x4*>(lds.region);
+            for (int i = tid; i < XS_SETS * XS_SET_BYTES / 16; i += QTHREADS) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();
+        char* sets = reinterpret_cast<char*>(lds.region);
+        int xa[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xa[j] = (rank * XP_W + file) * XS_POS_BYTES + ((j + hl + rank) & 3) * 16;
+        int wa[2];
+#pragma unroll
+        for (int cq = 0; cq < 2; ++cq) wa[cq] = ((rank + 1) * XP_W + file + 1) * XS_POS_BYTES + ((2 * hl + cq + rank + 1) & 3) * 16;
+        auto store_planes = [&](char* set, const f32x16& v) {   // ReLU, three terms, 2 x 3 16-byte stores (eval_f32.hip)
+#pragma unroll
+            for (int cq = 0; cq < 2; ++cq) {
+                u32x4 th, tm, tl;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    unsigned h_, m_, l_;
+                    split3(relu(v[8 * cq + 2 * d]), relu(v[8 * cq + 2 * d + 1]), h_, m_, l_);
+                    th[d] = h_; tm[d] = m_; tl[d] = l_;
+                }
+                *reinterpret_cast<u32x4*>(set + wa[cq]) = th;
+                *reinterpret_cast<u32x4*>(set + wa[cq] + XS_PLANE_BYTES) = tm;
+                *reinterpret_cast<u32x4*>(set + wa[cq] + 2 * XS_PLANE_BYTES) = tl;
+            }
+        };
+        store_planes(sets + m * XS_SET_BYTES, acc3);   // x3: this wave's chunk m of its half board
+        __syncthreads();
+        BFQ_STAMP(5);
+        // the six 3x3 layers: waves (half, 0) on the large-batch kernel's 32 x 32 tiles; the others keep the barriers
+        f32x16 acc;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[t] = pick(hl, bias[kBiasX4 + rowmap(t, 0)], bias[kBiasX4 + rowmap(t, 1)]);
+        auto coff = [](int i) { return i * 64; };
+        GStream<11, decltype(coff)> cs(wstream + (size_t)(kInputGroups + kC2Tiles * PER) * 64 + lane, coff,
+                                       m == 0 ? 9 * kConvSplitChunkGroups : 0);
+        if (m == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) conv3x3_chunk_split_q(cs, q * kConvSplitChunkGroups, sets + q * XS_SET_BYTES, xa, acc);
+        }
+        BFQ_STAMP(6);
+#pragma unroll
+        for (int layer = 0; layer < 5; ++layer) {
+            char* set = sets + (4 + (layer & 1)) * XS_SET_BYTES;
+            if (m == 0) store_planes(set, acc);
+            __syncthreads();
+            if (m == 0) {
+                const float* bl = bias + kBiasX4 + 32 * (layer + 1);
+#pragma unroll
+                for (int t = 0; t < 16; ++t) acc[t] = pick(hl, bl[rowmap(t, 0)], bl[rowmap(t, 1)]);
+                conv3x3_chunk_split_q(cs, (4 + layer) * kConvSplitChunkGroups, set, xa, acc);
+            }
+        }
+        if (MODE == 2) {
+            if (m == 0) {
+                float* out = scores + (size_t)board * 2048;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) out[rowmap(t, hl) * 64 + sq] = relu(acc[t]);
+            }
+#ifdef BFQ_STAMPS
+            BFQ_STAMP(7);
+            if (board == 0 && lane == 0) {
+                long long* so = reinterpret_cast<long long*>(scores + (size_t)n_boards * 2048) + wave * 8;
+                for (int i = 0; i < 8; ++i) so[i] = stamps[i];
+            }
+#endif
+            return;
+        }
+        // head: k_eval_f32's, by the two waves that hold x9 (threads 0 .. 127), scratch behind the planes
+        float* red = lds.region + XS_RED_OFF;
+        if (tid < 128) {
+            float part[16];
+#pragma unroll
+            for (int co = 0; co < 16; ++co) part[co] = 0.0f;
+            const f32x4* hw = headw + (size_t)half * 64 * 64 + lane;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float v = relu(acc[t]);
+#pragma unroll
+                for (int cq = 0; cq < 4; ++cq) {
+                    const f32x4 w = hw[(t * 4 + cq) * 64];
+                    part[4 * cq + 0] = fmaf(v, w.x, part[4 * cq + 0]);
+                    part[4 * cq + 1] = fmaf(v, w.y, part[4 * cq + 1]);
+                    part[4 * cq + 2] = fmaf(v, w.z, part[4 * cq + 2]);
+                    part[4 * cq + 3] = fmaf(v, w.w, part[4 * cq + 3]);
+                }
+            }
+#pragma unroll
+            for (int co = 0; co < 16; ++co) red[tid * RED_STRIDE + co] = part[co];
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int co = tid & 15, seg = tid >> 4;
+            float s = 0.0f;
+            for (int j = 0; j < 32; ++j) s += red[(seg * 32 + j) * RED_STRIDE + co];
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            const float y = fmaxf(s + bias[kBiasX10 + co], 0.0f);
+            float v = y * bias[kLogitW + co];
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 4);
+            v += __shfl_xor(v, 8);
+            if (tid == 0) scores[board] = v;
+        }
+    } else {
     BFQ_STAMP(1);
     // ---- 236 -> 512: hidden tiles 4m .. 4m+3, ReLU, to LDS as the B fragments of the next layer
     {
@@ -411,24 +676,33 @@ __global__ __launch_bounds__(QTHREADS, 1) void k_eval_f32q(const uint8_t* __rest
         v += __shfl_xor(v, 8);
         if (tid == 0) scores[board] = v;
     }
+    }
 }
 
 }  // namespace
 
-hipError_t launch_eval_f32q(const uint8_t* d_mailbox, size_t n, const float* d_packed, float* d_scores, hipStream_t stream) {
+template <int MODE>
+static hipError_t launch_q(int split, const uint8_t* d_mailbox, size_t n, const float* d_packed, float* d_out, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL((k_eval_f32q<0>), dim3((unsigned)n), dim3(QTHREADS), 0, stream, d_mailbox, (unsigned)n,
-                       reinterpret_cast<const f32x4*>(d_packed + kOffStream), d_packed + kOffBias,
-                       reinterpret_cast<const f32x4*>(d_packed + kOffHead), d_scores);
+    const f32x4* ws = reinterpret_cast<const f32x4*>(d_packed + kOffStream);
+    const float* bias = d_packed + kOffBias;
+    const f32x4* head = reinterpret_cast<const f32x4*>(d_packed + kOffHead);
+    if (split == 2)
+        hipLaunchKernelGGL((k_eval_f32q<MODE, 2>), dim3((unsigned)n), dim3(QTHREADS), 0, stream, d_mailbox, (unsigned)n, ws, bias, head, d_out);
+    else if (split == 1)
+        hipLaunchKernelGGL((k_eval_f32q<MODE, 1>), dim3((unsigned)n), dim3(QTHREADS), 0, stream, d_mailbox, (unsigned)n, ws, bias, head, d_out);
+    else
+        hipLaunchKernelGGL((k_eval_f32q<MODE, 0>), dim3((unsigned)n), dim3(QTHREADS), 0, stream, d_mailbox, (unsigned)n, ws, bias, head, d_out);
     return hipGetLastError();
 }
 
-hipError_t launch_policy_features_f32q(const uint8_t* d_mailbox, size_t n, const float* d_packed, float* d_x9, hipStream_t stream) {
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL((k_eval_f32q<2>), dim3((unsigned)n), dim3(QTHREADS), 0, stream, d_mailbox, (unsigned)n,
-                       reinterpret_cast<const f32x4*>(d_packed + kOffStream), d_packed + kOffBias,
-                       reinterpret_cast<const f32x4*>(d_packed + kOffHead), d_x9);
-    return hipGetLastError();
+hipError_t launch_eval_f32q(const uint8_t* d_mailbox, size_t n, const float* d_packed, float* d_scores, hipStream_t stream, int split) {
+    return launch_q<0>(split, d_mailbox, n, d_packed, d_scores, stream);
+}
+
+hipError_t launch_policy_features_f32q(const uint8_t* d_mailbox, size_t n, const float* d_packed, float* d_x9, hipStream_t stream,
+                                       int split) {
+    return launch_q<2>(split, d_mailbox, n, d_packed, d_x9, stream);
 }
 
 }  // namespace bf

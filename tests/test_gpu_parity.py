@@ -455,16 +455,19 @@ def test_f32_split_precision_scores_within_the_fp32_bound(torch_mod, golden, dty
         ctx.close()
 
 
-def test_fp32_small_calls_run_another_kernel_with_the_same_bits(torch_mod, golden):
+@pytest.mark.parametrize("dtype", ["f32", "f32s", "f32s3"])
+def test_fp32_small_calls_run_another_kernel_with_the_same_bits(torch_mod, golden, dtype):
     """A float32 context runs calls of up to 256 boards on k_eval_f32q (one board per workgroup, eight waves, 16 x 16
     tiles for the 3x3 layers: eval_f32q.hip) and larger ones on k_eval_f32.  Both fp32 MFMA shapes are fmaf chains in k
     order (tools/mfma_shape_bits.hip) and the small kernel keeps every layer's order of k, so a board's score and the
     move-scoring network's features must not depend on the size of the call it travels in: bit equality over call
     sizes around every switch, for mailbox, record and wire input, value network and move-scoring features
-    (as test_gpu_bf16.py does for k_eval_t16s)."""
+    (as test_gpu_bf16.py does for k_eval_t16s).  The split precisions (f32s, f32s3) take the same
+    route with their bf16-term products: the same 32 x 32 x 16 MFMAs per output tile in the same order, the hidden layer
+    exchanged as float32 and split by its readers."""
     from batch_first_amd import ops
     w = W.make_weights(seed=1234, bn="perturbed")
-    ctx = ops.DeviceContext(w, device=0)
+    ctx = ops.DeviceContext(w, device=0, dtype=dtype)
     try:
         ctx.set_policy(W.make_policy_weights(seed=4321))
         recs = torch_mod.from_numpy(golden["records"].copy()).cuda()
@@ -487,7 +490,7 @@ def test_fp32_small_calls_run_another_kernel_with_the_same_bits(torch_mod, golde
         ctx.close()
     # the reference's callable (wire format, host arrays) at a small and a large size
     from batch_first_amd import chestimator
-    bp, _, closer = chestimator.get_inference_functions(W.to_blob(w))
+    bp, _, closer = chestimator.get_inference_functions(W.to_blob(w), dtype=dtype)
     try:
         structs = np.frombuffer(golden["records"].tobytes(), dtype=P.COMPACT_DTYPE)
         whole = bp(golden["piece_filters"], golden["occupied_bbs"])

@@ -9,7 +9,8 @@ sys.path.insert(0, ROOT)
 import torch
 from batch_first_amd import _lib, ops, positions, weights
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-ctx = ops.DeviceContext(weights.make_weights(seed=1234, bn="perturbed"), device=0, dtype="f32")
+DT = sys.argv[2] if len(sys.argv) > 2 else "f32"
+ctx = ops.DeviceContext(weights.make_weights(seed=1234, bn="perturbed"), device=0, dtype=DT)
 ctx.set_policy(weights.make_policy_weights(seed=4321))
 recs = ops.records_to_tensor(positions.to_compact(positions.random_structs(n, seed=7)), torch.device("cuda", 0))
 x9 = torch.zeros((n + 1, 2048), dtype=torch.float32, device="cuda")
