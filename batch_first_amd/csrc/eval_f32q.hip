@@ -9,9 +9,10 @@
 // output element, a chain of fused multiply-adds in k order (tools/mfma_shape_bits.hip: 0 of 1 024 elements differ from
 // fmaf on the host).  So only the ORDER of k per element is part of the result, not the tiling, and every layer below
 // keeps k_eval_f32's order:
-//   stage 1   the four waves of a half board share the nine input convs (the bf16 three-term form of k_eval_f32, same
-//             instruction, same sequence per accumulator) and exchange x1 through LDS; every wave then holds its
-//             half's x1 in 118 registers;
+//   stage 1   the eight waves share the nine input convs, each computing its row tiles for both halves of the board
+//             (the bf16 three-term form of k_eval_f32, same instruction, same sequence per accumulator; every weight
+//             group crosses the L1 once) and exchange x1 through LDS; every wave then holds its half's x1 in 118
+//             registers;
 //   236->512  wave (half, m) takes hidden tiles 4m .. 4m+3 and leaves them, after ReLU, in LDS;
 //   512->128  wave (half, m) takes output tile m over all sixteen hidden tiles in order, B operands from LDS;
 //   3x3       32 output channels are ONE 32-row tile, which 32x32 tiles cannot spread over more than two waves: these
@@ -126,49 +127,62 @@ constexpr int input_group_base(int conv) {
     return g;
 }
 
-// Stage 1, one input conv: k_eval_f32's input_conv, instruction for instruction, with its weights straight from L2
-// (a stream of its own per conv, 15 groups ahead: one 32-cycle MFMA a group) and its result, after ReLU, to the x1
-// exchange in LDS: x1buf[register][half][lane], register r = channels 2r / 2r+1 of the lane halves as in k_eval_f32.
-template <int I>
-__device__ __forceinline__ void input_conv(const f32x4* __restrict__ wstream, int lane, const unsigned char* mb_center, int hl,
-                                           const float* __restrict__ bias, float* x1buf_lane) {
+// Stage 1: row tiles T0 .. T0 + NT - 1 of input conv I for BOTH halves of the board: k_eval_f32's input_conv,
+// instruction for instruction per accumulator, with every weight group fetched once per workgroup (straight from L2,
+// 15 groups ahead: two 32-cycle MFMAs a group) and the results, after ReLU, to the x1 exchange in LDS:
+// x1buf[register][half][lane], register r = channels 2r / 2r+1 of the lane halves as in k_eval_f32.
+// mb0 / mb1: the mailbox at the lane's square of half 0 / 1.
+template <int I, int T0, int NT>
+__device__ __forceinline__ void input_conv(const f32x4* __restrict__ wstream, int lane, const unsigned char* mb0,
+                                           const unsigned char* mb1, int hl, const float* __restrict__ bias, float* x1buf_lane) {
     constexpr InputConv cv = kInputConvs[I];
-    constexpr int G0 = input_group_base(I), NG = cv.k * cv.k * cv.tiles * kInputSplits;
+    constexpr int G0 = input_group_base(I), NG = cv.k * cv.k * NT * kInputSplits;
     constexpr int ph = ((cv.k - 1) * cv.dh) / 2, pw = ((cv.k - 1) * cv.dw) / 2;
-    auto off = [](int i) { return i * 64; };
+    static_assert(T0 + NT <= cv.tiles, "");
+    // the i-th group this call consumes: (tap, tile T0 + tl, split term), tap-major as the stream is
+    auto off = [](int i) { return (((i / kInputSplits) / NT * cv.tiles + T0 + (i / kInputSplits) % NT) * kInputSplits + i % kInputSplits) * 64; };
     GStream<15, decltype(off)> ws(wstream + (size_t)G0 * 64 + lane, off, NG);
-    f32x16 acc[cv.tiles];
+    f32x16 acc[NT][2];
 #pragma unroll
-    for (int tile = 0; tile < cv.tiles; ++tile)
+    for (int tl = 0; tl < NT; ++tl)
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            const int c = 32 * tile + 2 * t;
-            acc[tile][t] = (c < cv.ch) ? pick(hl, bias[kBiasX1 + cv.chan_base + c], bias[kBiasX1 + cv.chan_base + c + 1]) : 0.0f;
+            const int c = 32 * (T0 + tl) + 2 * t;
+            acc[tl][0][t] = acc[tl][1][t] =
+                (c < cv.ch) ? pick(hl, bias[kBiasX1 + cv.chan_base + c], bias[kBiasX1 + cv.chan_base + c + 1]) : 0.0f;
         }
-#pragma unroll
-    for (int tap = 0; tap < cv.k * cv.k; ++tap) {
-        const int dr = (tap / cv.k) * cv.dh - ph, df = (tap % cv.k) * cv.dw - pw;
-        const unsigned cc = (unsigned)((int)mb_center[dr * MB_W + df] - 8 * hl);
+    auto onehot = [&](const unsigned char* mbc, int dr, int df) {
+        const unsigned cc = (unsigned)((int)mbc[dr * MB_W + df] - 8 * hl);
         const unsigned one = (cc < 8u) ? (0x3F80u << ((cc & 1u) * 16u)) : 0u;
         u32x4 bu;
         bu.x = ((cc >> 1) == 0u) ? one : 0u;
         bu.y = ((cc >> 1) == 1u) ? one : 0u;
         bu.z = ((cc >> 1) == 2u) ? one : 0u;
         bu.w = ((cc >> 1) == 3u) ? one : 0u;
-        const bf16x8 b = __builtin_bit_cast(bf16x8, bu);
+        return __builtin_bit_cast(bf16x8, bu);
+    };
 #pragma unroll
-        for (int tile = 0; tile < cv.tiles; ++tile)
+    for (int tap = 0; tap < cv.k * cv.k; ++tap) {
+        const int dr = (tap / cv.k) * cv.dh - ph, df = (tap % cv.k) * cv.dw - pw;
+        const bf16x8 b0 = onehot(mb0, dr, df), b1 = onehot(mb1, dr, df);
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl)
 #pragma unroll
             for (int sp = 0; sp < kInputSplits; ++sp) {
-                const f32x4 w = ws.take((tap * cv.tiles + tile) * kInputSplits + sp);
-                acc[tile] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), b, acc[tile], 0, 0, 0);
+                const bf16x8 w = __builtin_bit_cast(bf16x8, ws.take((tap * NT + tl) * kInputSplits + sp));
+                acc[tl][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, b0, acc[tl][0], 0, 0, 0);
+                acc[tl][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, b1, acc[tl][1], 0, 0, 0);
             }
     }
 #pragma unroll
-    for (int tile = 0; tile < cv.tiles; ++tile)
+    for (int tl = 0; tl < NT; ++tl)
 #pragma unroll
         for (int t = 0; t < 16; ++t)
-            if (32 * tile + 2 * t < cv.ch) x1buf_lane[(cv.chan_base / 2 + 16 * tile + t) * 128] = relu(acc[tile][t]);
+            if (32 * (T0 + tl) + 2 * t < cv.ch) {
+                float* x = x1buf_lane + (cv.chan_base / 2 + 16 * (T0 + tl) + t) * 128;
+                x[0] = relu(acc[tl][0][t]);
+                x[64] = relu(acc[tl][1][t]);
+            }
 }
 
 // One 3x3 SAME conv over a 32-channel chunk in a zero-haloed plane, for this wave's 16 output channels x 16 squares:
@@ -303,26 +317,31 @@ __global__ __launch_bounds__(QTHREADS, 1) void k_eval_f32q(const uint8_t* __rest
     }
     __syncthreads();
 
-    // ---- stage 1: the four waves of a half board share the nine input convs (18 / 18 / 22 / 22 (tap, tile) pairs) and
-    // hand their channels to each other through LDS; then every wave holds x1 of its half in 118 registers
+    // ---- stage 1: the eight waves share the nine input convs, each computing its row tiles for BOTH halves of the board
+    // (9, 9, 9, 9, 9, 9, 13, 13 (tap, tile) pairs: every weight group crosses the L1 once per workgroup), and hand their
+    // channels to each other through LDS; then every wave holds x1 of its half in 118 registers
     float x1[kX1Regs];
     {
-        const unsigned char* mbc = &lds.mb[(rank + 7) * MB_W + file + 7];
-        float* xl = lds.region + half * 64 + lane;
-        if (m == 0) {
-            input_conv<0>(wstream, lane, mbc, hl, bias, xl);
-        } else if (m == 1) {
-            input_conv<1>(wstream, lane, mbc, hl, bias, xl);
-            input_conv<2>(wstream, lane, mbc, hl, bias, xl);
-        } else if (m == 2) {
-            input_conv<3>(wstream, lane, mbc, hl, bias, xl);
-            input_conv<4>(wstream, lane, mbc, hl, bias, xl);
-            input_conv<7>(wstream, lane, mbc, hl, bias, xl);
-        } else {
-            input_conv<5>(wstream, lane, mbc, hl, bias, xl);
-            input_conv<6>(wstream, lane, mbc, hl, bias, xl);
-            input_conv<8>(wstream, lane, mbc, hl, bias, xl);
+        const unsigned char* mb0 = &lds.mb[((ln >> 3) + 7) * MB_W + (ln & 7) + 7];   // square ln of half 0
+        const unsigned char* mb1 = mb0 + 4 * MB_W;                                   // square 32 + ln
+        float* xe = lds.region + lane;
+        switch (wave) {
+            case 0: input_conv<0, 0, 1>(wstream, lane, mb0, mb1, hl, bias, xe); break;
+            case 1: input_conv<0, 1, 1>(wstream, lane, mb0, mb1, hl, bias, xe); break;
+            case 2: input_conv<1, 0, 1>(wstream, lane, mb0, mb1, hl, bias, xe); break;
+            case 3: input_conv<2, 0, 1>(wstream, lane, mb0, mb1, hl, bias, xe); break;
+            case 4: input_conv<3, 0, 1>(wstream, lane, mb0, mb1, hl, bias, xe); break;
+            case 5: input_conv<4, 0, 1>(wstream, lane, mb0, mb1, hl, bias, xe); break;
+            case 6:
+                input_conv<5, 0, 1>(wstream, lane, mb0, mb1, hl, bias, xe);
+                input_conv<7, 0, 1>(wstream, lane, mb0, mb1, hl, bias, xe);
+                break;
+            default:
+                input_conv<6, 0, 1>(wstream, lane, mb0, mb1, hl, bias, xe);
+                input_conv<8, 0, 1>(wstream, lane, mb0, mb1, hl, bias, xe);
+                break;
         }
+        float* xl = lds.region + half * 64 + lane;
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < kX1Regs; ++r) x1[r] = xl[r * 128];
